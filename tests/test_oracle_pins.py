@@ -159,13 +159,13 @@ def test_finite_differences(data, pp):
         r, k = rng.integers(0, 7), rng.integers(0, 16)
         if P[r, k] == 0.0:
             continue
-        h = 1e-6 * P[r, k]
+        h = 1e-3 * P[r, k]
         Pp, Pm = P.copy(), P.copy()
         Pp[r, k] += h
         Pm[r, k] -= h
         fd = (cport.batch(Pp[None, None], d[None], [0], 0, grad=False)[0, 0]
               - cport.batch(Pm[None, None], d[None], [0], 0, grad=False)[0, 0]) / (2 * h)
-        np.testing.assert_allclose(g[r, k], fd, rtol=1e-2, atol=1e-6)  # tests/test_gpu.py:29-31 uses 1e-2
+        np.testing.assert_allclose(g[r, k], fd, rtol=1e-2, atol=1e-3)  # tests/test_gpu.py:29-31 uses 1e-2
 
 
 def test_warmup_equals_two_step(missing_data, pp):
