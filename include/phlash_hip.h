@@ -1,0 +1,96 @@
+/* libphlash_hip.so -- C ABI of the MI355X (gfx950) PSMC likelihood engine.
+ *
+ * Drop-in boundary for the *kernel plugin* of jthlab/phlash (v1.0.6).  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repo):
+ *
+ *   phk_create / phk_destroy   <->  _PSMCKernelBase.__init__ / __del__      src/phlash/gpu.py:101-174
+ *                                   (validate + upload the int8 het matrix once, own it for life)
+ *   phk_loglik                 <->  _PSMCKernelBase.__call__ + the two CUDA entry points
+ *                                   `loglik` / `loglik_grad`                 src/phlash/gpu.py:182-325,
+ *                                                                           529-538, 575-586
+ *   phk_device_count           <->  PSMCKernel._initialize_devices           src/phlash/gpu.py:369-384
+ *   phk_last_error             <->  CudaError / ASSERT_DRV                   src/phlash/gpu.py:23-46
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns PHK_OK (0) or a PHK_E* code; the message of the
+ *     last failure on the calling thread is phk_last_error().
+ *   - `params`, `inds`, `ll`, `grad` are DEVICE pointers (e.g. torch tensors' data_ptr()): nothing
+ *     bounces through the host.  `data` of phk_create may be host or device memory.
+ *   - calls on one handle are stream-ordered on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and return without synchronising.  A handle is not re-entrant (it owns
+ *     scratch buffers), exactly like a reference kernel object (gpu.py:222-237).
+ *   - parameter block layout [B, S or 1, 7, K], rows b,d,u,v,emis0,emis1,pi (gpu.py:189, 496-501),
+ *     element type float (double_precision = 0) or double (1) (gpu.py:133-136).
+ */
+#ifndef PHLASH_HIP_H
+#define PHLASH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHK_OK 0
+#define PHK_EINVAL 1   /* bad argument (the reference raises AssertionError: gpu.py:106-113,197-214) */
+#define PHK_ENOMEM 2   /* device allocation failed (the reference raises MemoryError: gpu.py:117-124) */
+#define PHK_EHIP 3     /* HIP runtime error (the reference raises CudaError/RuntimeError) */
+#define PHK_EUNSUPPORTED 4 /* K / variant not compiled in */
+
+typedef struct phk_handle phk_handle;
+
+/* ABI version of this library (major*1000 + minor). */
+int phk_version(void);
+
+/* Message of the last failure on this thread ("" if none).  Never NULL. */
+const char* phk_last_error(void);
+
+/* Number of visible HIP devices. */
+int phk_device_count(int* n);
+
+/* Create a kernel object for K hidden states over the observation matrix data[N][L]
+ * (int8, values -1 missing / 0 hom / >=1 het; values above 1 are clipped to 1 and values below -1
+ * rejected, as gpu.py:106-110; rows that are entirely missing are rejected as gpu.py:111-113).
+ * The matrix is re-packed on the device to a private 2-bit layout; `data` is not referenced after
+ * the call returns.  K in {4,8,16,32,64}. */
+int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L,
+               int data_on_device, int double_precision, int device);
+
+int phk_destroy(phk_handle* h);
+
+/* One evaluation over B particles x S chunks.
+ *   params     device, [B, S, 7, K] with element strides (pstride_b, pstride_s); pstride_s = 0
+ *              broadcasts one [7,K] block of a particle over all S chunks.
+ *   inds       device int64 [S]: row of `data` for each chunk.  The range 0 <= inds[s] < N is the
+ *              caller's contract (the Python host checks it as gpu.py:197-199 before the call).
+ *   W          number of leading sites of every row that are run but NOT scored (the reference's
+ *              warm-up prefix, model.py:52-55).  W = 0 reproduces `loglik`/`loglik_grad` exactly:
+ *              pi is the state law one transition before site 0.
+ *   ll         device double [B, S]: log-likelihood of sites W..L-1 of chunk s under particle b
+ *   grad       device [B, S, 7, K] (float or double as the handle) or NULL for the no-gradient
+ *              kernel.  grad_dlog = 0: d ll / d theta.  grad_dlog = 1: theta * d ll / d theta, the
+ *              quantity the reference kernel returns (gpu.py:647-653,686-691), every row in natural
+ *              index order (i.e. after the reference's np.roll of the v row, gpu.py:307-309).
+ */
+int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s,
+               const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad,
+               int grad_dlog, void* stream);
+
+/* Tuning / introspection (no reference counterpart).
+ * R = lanes per sequence (1,2,4,8,16; must divide K, K/R <= 16), T = checkpoint block (8 or 16).
+ * 0 = choose automatically from B*S. */
+int phk_set_variant(phk_handle* h, int R, int T);
+int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T);
+/* Upper bound for the checkpoint workspace; larger problems are run in particle / chunk slabs. */
+int phk_set_workspace_limit(phk_handle* h, int64_t bytes);
+int64_t phk_workspace_bytes(phk_handle* h);
+/* With profiling on, every phk_loglik records HIP events around its kernels on the call's stream;
+ * phk_last_timing waits for them and returns the summed device time of the forward and backward
+ * kernels of the last call (ms) and the number of launches of each. */
+int phk_set_profiling(phk_handle* h, int on);
+int phk_last_timing(phk_handle* h, float* fwd_ms, float* bwd_ms, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

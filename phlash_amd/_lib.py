@@ -1,0 +1,77 @@
+"""ctypes binding of ``libphlash_hip.so`` (C ABI declared in ``include/phlash_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing, or a call fails, this
+module raises -- it never routes through ``oracle/``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphlash_hip.so")
+
+PHK_OK, PHK_EINVAL, PHK_ENOMEM, PHK_EHIP, PHK_EUNSUPPORTED = 0, 1, 2, 3, 4
+
+# every symbol include/phlash_hip.h declares: (restype, argtypes)
+_vp, _i, _i64, _dp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)
+_ip, _fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+SIGNATURES = {
+    "phk_version": (_i, []),
+    "phk_last_error": (ctypes.c_char_p, []),
+    "phk_device_count": (_i, [_ip]),
+    "phk_create": (_i, [ctypes.POINTER(_vp), _i, _vp, _i64, _i64, _i, _i, _i]),
+    "phk_destroy": (_i, [_vp]),
+    "phk_loglik": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "phk_set_variant": (_i, [_vp, _i, _i]),
+    "phk_get_variant": (_i, [_vp, _i64, _i64, _ip, _ip]),
+    "phk_set_workspace_limit": (_i, [_vp, _i64]),
+    "phk_workspace_bytes": (_i64, [_vp]),
+    "phk_set_profiling": (_i, [_vp, _i]),
+    "phk_last_timing": (_i, [_vp, _fp, _fp, _ip]),
+}
+
+
+class HipError(RuntimeError):
+    """A HIP runtime failure inside the library (the reference raises CudaError, gpu.py:23-32)."""
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Load the library once (reference: CudaInitializer, gpu.py:73-99).  Raises ImportError when
+    the in-tree build is missing -- build it with ``python -c 'import __graft_entry__ as g; g.build()'``
+    or ``make -C phlash_amd/csrc``."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: the HIP extension is not built (make -C phlash_amd/csrc). "
+                    "phlash_amd has no CPU fallback."
+                )
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    """Map a PHK_E* status to the exception the reference raises for the same condition."""
+    if rc == PHK_OK:
+        return
+    msg = load().phk_last_error().decode(errors="replace")
+    if rc == PHK_EINVAL:
+        raise AssertionError(msg)  # gpu.py:106-113, 197-214 are asserts
+    if rc == PHK_ENOMEM:
+        raise MemoryError(msg)  # gpu.py:117-124
+    if rc == PHK_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipError(msg)

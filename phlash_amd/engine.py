@@ -1,0 +1,103 @@
+"""Thin device-side wrapper around one ``phk_handle``: torch tensors in, torch tensors out.
+
+This is the layer the reference has in ``_PSMCKernelBase`` (src/phlash/gpu.py:101-325), minus the
+per-call host<->device traffic: parameters, indices, log-likelihoods and gradients are torch tensors
+on the handle's GPU, passed to the C ABI by pointer.  PyTorch is plumbing here (device memory and
+streams); all arithmetic on the path happens in the HIP kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class HipEngine:
+    def __init__(self, K: int, data, double_precision: bool = False, device: int = 0):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: phlash_amd needs an MI355X (there is no CPU fallback)")
+        self.K = int(K)
+        self.double_precision = bool(double_precision)
+        self.device = torch.device("cuda", int(device))
+        self.dtype = torch.float64 if double_precision else torch.float32
+        self._h = ctypes.c_void_p()
+        if isinstance(data, torch.Tensor) and data.is_cuda:
+            # device-resident matrix: validate with torch (gpu.py:103-113), hand over the pointer
+            assert data.ndim == 2 and data.dtype == torch.int8
+            assert int(data.min()) >= -1
+            assert bool((data.max(dim=1).values > -1).all()), "data contains observations with all missing values"
+            d = data.contiguous()
+            self.N, self.L = d.shape
+            rc = lib.phk_create(ctypes.byref(self._h), self.K, d.data_ptr(), self.N, self.L, 1, int(double_precision), int(device))
+        else:
+            d = np.asarray(data)
+            assert d.ndim == 2  # gpu.py:103
+            assert d.dtype == np.int8  # gpu.py:104
+            d = np.ascontiguousarray(d)
+            self.N, self.L = d.shape
+            rc = lib.phk_create(ctypes.byref(self._h), self.K, d.ctypes.data, self.N, self.L, 0, int(double_precision), int(device))
+        _lib.check(rc)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.load().phk_destroy(h)
+
+    def __del__(self):  # gpu.py:153-174
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tuning / introspection -----------------------------------------------------------
+    def set_variant(self, R: int = 0, T: int = 0):
+        _lib.check(_lib.load().phk_set_variant(self._h, int(R), int(T)))
+
+    def get_variant(self, B: int, S: int) -> tuple[int, int]:
+        r, t = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().phk_get_variant(self._h, int(B), int(S), ctypes.byref(r), ctypes.byref(t)))
+        return r.value, t.value
+
+    def set_workspace_limit(self, nbytes: int):
+        _lib.check(_lib.load().phk_set_workspace_limit(self._h, int(nbytes)))
+
+    def workspace_bytes(self) -> int:
+        return int(_lib.load().phk_workspace_bytes(self._h))
+
+    def set_profiling(self, on: bool):
+        _lib.check(_lib.load().phk_set_profiling(self._h, int(bool(on))))
+
+    def last_timing(self) -> tuple[float, float, int]:
+        f, b, n = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+        _lib.check(_lib.load().phk_last_timing(self._h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
+        return f.value, b.value, n.value
+
+    # ---- the operator -----------------------------------------------------------------------
+    def run(self, params: torch.Tensor, inds: torch.Tensor, warmup: int = 0, grad: bool = True, dlog: bool = False):
+        """params [B, S, 7, K] or [B, 1, 7, K] (one block per particle, broadcast over the chunks);
+        inds int64 [S] on the device.  Returns ll [B, S] float64 and, if ``grad``, d ll/d params
+        [B, S, 7, K] in the handle's float type (``dlog``: theta * d ll/d theta)."""
+        assert params.is_cuda and inds.is_cuda and params.device == self.device
+        assert params.ndim == 4 and params.shape[2] == 7 and params.shape[3] == self.K, params.shape
+        assert inds.ndim == 1 and inds.dtype == torch.int64
+        B, Sp = params.shape[0], params.shape[1]
+        S = inds.shape[0]
+        assert Sp in (1, S)
+        p = params.to(self.dtype).contiguous()
+        inds = inds.contiguous()
+        ll = torch.empty((B, S), dtype=torch.float64, device=self.device)
+        g = torch.empty((B, S, 7, self.K), dtype=self.dtype, device=self.device) if grad else None
+        stride_b = Sp * 7 * self.K
+        stride_s = 7 * self.K if Sp == S else 0
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.load().phk_loglik(
+            self._h, p.data_ptr(), stride_b, stride_s, inds.data_ptr(), B, S, int(warmup),
+            ll.data_ptr(), g.data_ptr() if grad else None, int(bool(dlog)), ctypes.c_void_p(stream),
+        )
+        _lib.check(rc)
+        return (ll, g) if grad else ll

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the float64 CPU oracle on the same
+seeded inputs.  Tolerances: float64 kernels must agree to rounding; float32 kernels must hold the
+north-star bar of 1e-5 relative on the log-likelihood (BASELINE.json) and 2e-3 of the row scale on
+gradients (the reference's own tests accept 1e-3..1e-2: tests/test_model.py:17-19,
+tests/test_gpu.py:29-31)."""
+
+import numpy as np
+import pytest
+
+from oracle import cport
+from oracle import psmc_numpy as o
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _engine(K, data, dbl):
+    from phlash_amd.engine import HipEngine
+
+    return HipEngine(K, data, double_precision=dbl)
+
+
+def _params(K, B, S, seed, theta=1e-2):
+    """B particles around the default model (mcmc.py:186-195 style perturbation) -> [B,S,7,K]"""
+    rng = np.random.default_rng(seed)
+    pat = f"{K - 2}*1+1*2" if K > 4 else f"{K}*1"
+    P = len(o.parse_pattern(pat))
+    x0 = o.particle_from_linear(pat, 1e-4, 15.0, np.ones(P), theta, theta)
+    out = np.zeros((B, S, 7, K))
+    for b in range(B):
+        x = x0 + 0.3 * rng.normal(size=x0.shape) * (b > 0)
+        pp = o.from_dm(o.particle_to_dm(x, pat, theta))
+        out[b, :] = pp.stack()
+    return out
+
+
+def _run(eng, P, inds, W, grad=True, dlog=False):
+    p = torch.tensor(P, device="cuda")
+    i = torch.tensor(np.asarray(inds), dtype=torch.int64, device="cuda")
+    res = eng.run(p, i, warmup=W, grad=grad, dlog=dlog)
+    torch.cuda.synchronize()
+    if grad:
+        return res[0].cpu().numpy(), res[1].double().cpu().numpy()
+    return res.cpu().numpy()
+
+
+def _check(ll, g, ll_ref, g_ref, dbl):
+    if dbl:
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10, atol=1e-10)
+        gtol = 1e-8
+    else:
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
+        gtol = 2e-3
+    if g is not None:
+        scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
+        # pi row: with a warm-up prefix d ll/d pi is a difference of two nearly equal sweeps that
+        # decays to ~0 with W (the chain has forgotten pi); its natural scale is the O(1) of the
+        # W = 0 case (sum_i pi_i dll/dpi_i = 1), so never judge it against less than 1.
+        scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
+        err = np.abs(g - g_ref) / scale
+        assert err.max() < gtol, f"gradient error {err.max():.3e} (row-scaled) >= {gtol}"
+
+
+VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (2, 16), (4, 16), (16, 16)]
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+@pytest.mark.parametrize("R,T", VARIANTS_16)
+@pytest.mark.parametrize("W", [0, 100])
+def test_k16_all_variants(missing_data, R, T, W, dbl):
+    if dbl and (R, T) == (1, 16):
+        pytest.skip("f64 R=1 T=16 does not fit the LDS")
+    data = missing_data
+    eng = _engine(16, data, dbl)
+    try:
+        eng.set_variant(R, T)
+    except AssertionError:
+        pytest.skip("variant does not fit")
+    B, S = 3, len(data)
+    P = _params(16, B, 1, seed=7)
+    inds = np.arange(S)
+    ll, g = _run(eng, P, inds, W)
+    ll_ref, g_ref = cport.batch(P, data, inds, W)
+    _check(ll, g, ll_ref, g_ref, dbl)
+    # the no-gradient kernel gives the same ll (reference tests/test_gpu.py:34-40)
+    ll2 = _run(eng, P, inds, W, grad=False)
+    np.testing.assert_allclose(ll2, ll, rtol=1e-12 if dbl else 1e-7)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+@pytest.mark.parametrize("K,R", [(4, 1), (4, 4), (8, 2), (32, 2), (32, 16), (64, 4), (64, 16)])
+def test_other_K(K, R, dbl, rng):
+    data = (rng.uniform(size=(6, 700)) < 0.08).astype(np.int8)
+    data.flat[rng.integers(0, data.size, 40)] = -1
+    eng = _engine(K, data, dbl)
+    try:
+        eng.set_variant(R, 8)
+    except AssertionError:
+        pytest.skip("variant does not fit")
+    P = _params(K, 2, 1, seed=3)
+    inds = np.array([5, 0, 3, 3])
+    for W in (0, 64):
+        ll, g = _run(eng, P, inds, W)
+        ll_ref, g_ref = cport.batch(P, data, inds, W)
+        _check(ll, g, ll_ref, g_ref, dbl)
+
+
+@pytest.mark.parametrize("L", [1, 2, 7, 8, 9, 15, 16, 17, 33, 1003])
+def test_ragged_lengths(L, rng):
+    data = (rng.uniform(size=(3, L)) < 0.3).astype(np.int8)
+    data[:, 0] = np.maximum(data[:, 0], 0)
+    eng = _engine(16, data, True)
+    P = _params(16, 2, 1, seed=1)
+    inds = np.arange(3)
+    for R, T in [(1, 8), (4, 8), (16, 16)]:
+        eng.set_variant(R, T)
+        for W in sorted({0, min(3, L), L}):
+            ll, g = _run(eng, P, inds, W)
+            ll_ref, g_ref = cport.batch(P, data, inds, W)
+            _check(ll, g, ll_ref, g_ref, True)
+
+
+def test_per_chunk_params_and_dlog(data, rng):
+    """[B,S,7,K] parameters with a different pi per (b,s) -- the shape the reference feeds its kernel
+    after the warm-up (model.py:55) -- and the reference's d/dlog output convention."""
+    eng = _engine(16, data, True)
+    B, S = 2, 4
+    P = np.repeat(_params(16, B, 1, seed=11), S, axis=1)
+    pi = rng.dirichlet(np.ones(16), size=(B, S))
+    P[:, :, 6, :] = pi
+    inds = np.array([1, 9, 9, 0])
+    ll, g = _run(eng, P, inds, 0, dlog=True)
+    ll_ref, g_ref = cport.batch(P, data, inds, 0)
+    _check(ll, g, ll_ref, g_ref * P, True)
+
+
+def test_bruteforce_known_answer():
+    dm = o.DM(t=np.array([0.0, 0.3, 1.0, 2.5]), c=np.array([1.0, 2.0, 0.5, 1.5]), theta=0.3, rho=0.2)
+    pp = o.from_dm(dm)
+    A = o.dense_from_pp(pp)
+    rows = [[0, 1, -1, 0, 1], [1, 1, 0, 0, 0], [-1, 0, 0, 1, 1]]
+    data = np.array(rows, dtype=np.int8)
+    for dbl in (True, False):
+        eng = _engine(4, data, dbl)
+        ll = _run(eng, pp.stack()[None, None], np.arange(3), 0, grad=False)
+        for i, r in enumerate(rows):
+            want = o.psmc_ll_bruteforce(A, pp.emis0, pp.emis1, pp.pi, r)
+            np.testing.assert_allclose(ll[0, i], want, rtol=1e-12 if dbl else 1e-5)
+
+
+def test_golden_survey_values():
+    pp = o.from_dm(o.default_dm("16*1", 1e-2, 1e-2))
+    want = {0: -198.0182669767, 1: -204.3347458037, 2: -171.8032465847}
+    for seed, ll_want in want.items():
+        d = (np.random.default_rng(seed).uniform(size=(10, 1000)) < 0.05).astype(np.int8)
+        eng = _engine(16, d, True)
+        ll = _run(eng, pp.stack()[None, None], np.array([0]), 0, grad=False)
+        np.testing.assert_allclose(ll[0, 0], ll_want, rtol=1e-10)
+
+
+def test_slabbed_workspace_matches(data):
+    eng = _engine(16, data, False)
+    P = _params(16, 5, 1, seed=2)
+    inds = np.arange(10)
+    ll, g = _run(eng, P, inds, 50)
+    eng.set_workspace_limit(3 * 10 * 125 * 16 * 4)  # room for ~3 particles -> slabs of particles
+    ll2, g2 = _run(eng, P, inds, 50)
+    np.testing.assert_array_equal(ll, ll2)
+    np.testing.assert_array_equal(g, g2)
+    eng.set_workspace_limit(4 * 125 * 16 * 4)  # less than one particle -> slabs of chunks
+    ll3, g3 = _run(eng, P, inds, 50)
+    np.testing.assert_array_equal(ll, ll3)
+    np.testing.assert_array_equal(g, g3)
+
+
+def test_errors(data):
+    from phlash_amd.engine import HipEngine
+
+    with pytest.raises(NotImplementedError):
+        HipEngine(7, data)
+    bad = data.copy()
+    bad[3] = -1
+    with pytest.raises(AssertionError):
+        HipEngine(16, bad)
+    bad = data.copy()
+    bad[0, 0] = -2
+    with pytest.raises(AssertionError):
+        HipEngine(16, bad)
+    eng = HipEngine(16, data)
+    with pytest.raises(AssertionError):
+        eng.set_variant(3, 8)
+    with pytest.raises(AssertionError):
+        _run(eng, _params(16, 1, 1, 0), np.arange(2), 5000)
