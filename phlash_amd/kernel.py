@@ -1,0 +1,199 @@
+"""The kernel plugin: ``get_kernel(M, data, double_precision)`` -> an object with ``.loglik`` and
+``.__call__`` -- the drop-in boundary of the reference (src/phlash/kernel.py:7-24; protocol of
+``PSMCKernel`` src/phlash/gpu.py:328-438 and ``PureJaxPSMCKernel`` src/phlash/hmm.py:14-49).
+
+What differs from the reference, by design:
+* arrays are torch tensors on the GPU (numpy in -> numpy out is kept for the reference's call style);
+* ``loglik`` is a ``torch.autograd.Function`` instead of a ``jax.custom_vjp`` (gpu.py:441-472), and
+  it is natively batched over particles and chunks instead of being vmapped;
+* ``overlap=W`` (extension): rows of ``data`` then carry W leading warm-up sites that are run but
+  not scored, so the reference's separate warm-up scan + pi substitution (model.py:52-55) and its
+  AD happen inside the same kernel sweep;
+* there is **no fallback**: where the reference falls back to pure JAX on ImportError/RuntimeError
+  (kernel.py:14-24), this raises -- a silent CPU path would void every parity and speed claim.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+from .engine import HipEngine
+from .params import PSMCParams
+from .size_history import DemographicModel
+
+F64 = torch.float64
+
+
+def _as_tensor(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=F64)
+    return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=F64, device=device)
+
+
+class _LogLik(torch.autograd.Function):
+    """ll = kernel(params); backward = cotangent * stored d ll / d params (gpu.py:441-472: the fwd
+    rule runs the gradient kernel and the bwd rule scales the stored derivative)."""
+
+    @staticmethod
+    def forward(ctx, params, kern, inds, need_grad):
+        # params [B, S|1, 7, K] float64 on the device
+        if need_grad:
+            ll, g = kern._eng.run(params, inds, warmup=kern.overlap, grad=True, dlog=False)
+            ctx.save_for_backward(g)
+            ctx.bcast = params.shape[1] == 1 and inds.shape[0] > 1
+        else:
+            ll = kern._eng.run(params, inds, warmup=kern.overlap, grad=False)
+        return ll
+
+    @staticmethod
+    def backward(ctx, gll):
+        (g,) = ctx.saved_tensors
+        gp = gll[..., None, None] * g.to(F64)
+        if ctx.bcast:
+            gp = gp.sum(1, keepdim=True)
+        return gp, None, None, None
+
+
+class PSMCKernel:
+    """PSMC likelihood kernel on one MI355X.
+
+    Args (reference: gpu.py:328-350):
+        M: number of hidden states (4, 8, 16, 32 or 64; the reference is tuned for 16).
+        data: int8 [N, L] het matrix, values -1 (missing), 0, 1 (larger counts are clipped to 1).
+        double_precision: float64 kernels instead of float32.
+        num_gpus: accepted for signature compatibility.  One kernel object drives one GPU; scale
+            out with one process per GPU (``phlash_amd.parallel``), not with threads.
+        overlap: number of leading warm-up sites in every row (extension, default 0).
+        device: HIP device ordinal (default: torch's current device).
+    """
+
+    def __init__(self, M, data, double_precision=False, num_gpus: int = None, overlap: int = 0, device=None):
+        if num_gpus is not None:
+            assert num_gpus > 0  # gpu.py:340-341
+            if num_gpus > 1:
+                warnings.warn("num_gpus > 1 is ignored: one PSMCKernel drives one GPU; "
+                              "use phlash_amd.parallel (one process per GPU) to scale out")
+        if M != 16:
+            warnings.warn("Performance is optimized when M=16")  # gpu.py:128-129
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if isinstance(data, torch.Tensor):
+            if not data.is_cuda:
+                data = data.numpy()
+        if not isinstance(data, torch.Tensor):
+            data = np.asarray(data)
+            assert data.ndim == 2  # gpu.py:103
+            assert data.dtype == np.int8  # gpu.py:104
+            assert data.min() >= -1  # gpu.py:105
+            assert np.all(data.max(axis=1) > -1), "data contains observations with all missing values"
+        self.M = M
+        self.double_precision = double_precision
+        self.overlap = int(overlap)
+        self._eng = HipEngine(M, data, double_precision=double_precision, device=device)
+        self.N, self.L = self._eng.N, self._eng.L
+        assert 0 <= self.overlap <= self.L
+        self.device = self._eng.device
+
+    @property
+    def float_type(self):  # gpu.py:176-180
+        return np.float64 if self.double_precision else np.float32
+
+    # ---- shape handling (gpu.py:188-213) ----------------------------------------------------
+    def _prepare(self, pp: PSMCParams, index):
+        """-> params [B, S|1, 7, M] f64 on device, inds int64 [S] on device, (added_B, added_S)"""
+        dev = self.device
+        pa = torch.stack([_as_tensor(a, dev) for a in pp], -2)
+        if isinstance(index, torch.Tensor):
+            inds = index.to(device=dev, dtype=torch.int64)
+        else:
+            inds = torch.as_tensor(np.asarray(index), dtype=torch.int64, device=dev)
+        M = self.M
+        added_S = inds.ndim == 0
+        inds = torch.atleast_1d(inds)
+        assert inds.ndim == 1
+        S = inds.shape[0]
+        if S > 0:
+            lo, hi = int(inds.min()), int(inds.max())
+            assert 0 <= lo and hi < self.N, f"0 <= {lo} <= {hi} < N={self.N}"  # gpu.py:197-199
+        added_B = False
+        if pa.ndim == 2:  # one block for everything
+            assert pa.shape == (7, M)
+            pa = pa[None, None]
+            added_B = True
+        elif pa.ndim == 3:  # one block per chunk
+            assert pa.shape == (S, 7, M), (pa.shape, S)
+            pa = pa[None]
+            added_B = True
+        assert pa.ndim == 4 and pa.shape[2:] == (7, M)
+        assert pa.shape[1] in (1, S)
+        assert bool(torch.isfinite(pa).all()), "not all parameters finite"  # gpu.py:214
+        return pa, inds, added_B, added_S
+
+    @staticmethod
+    def _strip(x, added_B, added_S):
+        # gpu.py:318-325
+        if added_B and added_S:
+            return x[0, 0]
+        if added_B:
+            return x[0]
+        if added_S:
+            return x[:, 0]
+        return x
+
+    # ---- differentiable log-likelihood (gpu.py:359-367) --------------------------------------
+    def loglik(self, pp, index):
+        """Log-likelihood of chunk(s) ``index`` under ``pp`` (PSMCParams or DemographicModel;
+        fields [M], [S, M], [B, S, M], or [B, 1, M] = one block per particle broadcast over the chunks).  Returns a float64 tensor
+        of shape (), [S] or [B, S], differentiable w.r.t. the fields of ``pp`` by autograd."""
+        if isinstance(pp, DemographicModel):
+            pp = PSMCParams.from_dm(pp)  # convenience overload, gpu.py:364-367
+        dev = self.device
+        fields = [_as_tensor(a, dev) for a in pp]
+        pa, inds, added_B, added_S = self._prepare(PSMCParams(*fields), index)
+        need_grad = torch.is_grad_enabled() and pa.requires_grad
+        ll = _LogLik.apply(pa, self, inds, need_grad)
+        return self._strip(ll, added_B, added_S)
+
+    # ---- the raw operator (gpu.py:386-423, 182-325) ------------------------------------------
+    def __call__(self, pp: PSMCParams, index, grad: bool):
+        """ll (float64) or (ll, PSMCParams of d ll / d log(param)) -- the reference's operator:
+        the derivative is with respect to the LOG of each parameter (gpu.py:647-653, 686-691),
+        in ``float_type``, batch dims stripped as the reference strips them.  numpy in -> numpy
+        out; torch in -> torch out."""
+        want_numpy = not any(isinstance(a, torch.Tensor) for a in pp)
+        pa, inds, added_B, added_S = self._prepare(pp, index)
+        with torch.no_grad():
+            if grad:
+                ll, g = self._eng.run(pa, inds, warmup=self.overlap, grad=True, dlog=True)
+            else:
+                ll = self._eng.run(pa, inds, warmup=self.overlap, grad=False)
+        ll = self._strip(ll, added_B, added_S)
+        if want_numpy:
+            ll = ll.cpu().numpy()
+        if not grad:
+            return ll
+        dll = PSMCParams(*(self._strip(g[..., i, :], added_B, added_S) for i in range(7)))
+        if want_numpy:
+            dll = PSMCParams(*(a.cpu().numpy() for a in dll))
+        return ll, dll
+
+    # ---- fused evaluation used by the sampler -------------------------------------------------
+    def value_and_grad(self, pp: PSMCParams, inds: torch.Tensor, reduce_chunks: bool = True):
+        """One particle population against a minibatch: pp fields [B, M] -> (ll, d ll / d params).
+        With ``reduce_chunks`` the sum over the S chunks is taken here (ll [B], grad [B, 7, M]
+        float64) -- the quantity model.log_density needs (model.py:57 ``.sum()``)."""
+        pa = torch.stack([_as_tensor(a, self.device) for a in pp], -2)[:, None]
+        with torch.no_grad():
+            ll, g = self._eng.run(pa, inds, warmup=self.overlap, grad=True, dlog=False)
+        if reduce_chunks:
+            return ll.sum(1), g.sum(1, dtype=F64)
+        return ll, g
+
+
+def get_kernel(M: int, data, double_precision: bool = False, **kw) -> PSMCKernel:
+    """Reference signature (src/phlash/kernel.py:7).  Raises if the HIP library or a GPU is
+    missing -- there is deliberately no slower fallback to hide behind."""
+    return PSMCKernel(M=M, data=data, double_precision=double_precision, **kw)

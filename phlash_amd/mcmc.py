@@ -1,0 +1,208 @@
+"""``fit``: posterior sampling of size histories by SVGD.  Mirrors the reference's driver
+(src/phlash/mcmc.py:34-314): same option names and defaults, same data flow, same return type.
+The per-iteration step (mcmc.py:275-286) is the hot loop: particles -> PSMCParams (torch float64)
+-> HIP kernel (value + gradient, warm-up fused) -> chain rule by autograd -> SVGD/AMSGrad update.
+
+Differences from the reference, all deliberate:
+* the warm-up prefix of every chunk is evaluated inside the kernel (``overlap`` fused) instead of a
+  separate JAX scan that JAX then differentiates (model.py:52-55);
+* random numbers come from numpy/torch generators, not JAX's PRNG: runs are reproducible for a
+  given ``key`` (an int seed here) but not bit-identical to a JAX run;
+* SVGD / AMSGrad are the restatements in ``svgd.py`` (parity unpinned, see there);
+* under ``torchrun`` (one process per GPU) the chunk rows are sharded across ranks and each step
+  ends in one all-reduce (``parallel.py``); all ranks return the same particles.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+from . import parallel, svgd
+from .afs import bws_transform, fold_transform
+from .data import init_mcmc_data
+from .kernel import get_kernel
+from .model import afs_term, log_prior
+from .params import MCMCParams, PSMCParams
+from .size_history import DemographicModel, SizeHistory
+from .util import Pattern
+
+F64 = torch.float64
+
+
+def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, afs_transform):
+    """[B] log densities of the particles x [B, D] (model.py:24-73 batched; the HMM term is summed
+    over every rank's share of the minibatch)."""
+    mcp = template.from_flat(x)
+    dm = mcp.to_dm()
+    pp = PSMCParams.from_dm(dm)
+    l1 = log_prior(mcp)
+    l2 = parallel.sharded_loglik_sum(kern, pp, local_inds).to(x.device)
+    l3 = afs_term(dm, afs, afs_transform) if afs is not None and len(afs) > 1 else torch.zeros_like(l1)
+    ret = c[0] * l1 + c[1] * l2 + c[2] * l3
+    return torch.where(torch.isfinite(ret), ret, torch.full_like(ret, -float("inf")))
+
+
+def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
+    """Sample demographic models from the posterior.
+
+    Args:
+        data: list of contigs (objects with ``to_chunked`` / ``get_data``, e.g. ``RawContig``).
+        test_data: optional held-out contig for the expected log-predictive density (early stop).
+        **options: the reference's option set (mcmc.py:66-208): key, niter=1000, window_size=100,
+            overlap=500, chunk_size, max_samples=20, num_workers, mutation_rate, truth,
+            elpd_cutoff=100, afs_transform, minibatch_size, init, theta, t1=1e-4, tM=15.0,
+            rho_over_theta=1.0, alpha=0, beta=0, learning_rate=0.1, sigma=1.0, num_particles=500,
+            double_precision=False, callback, progress=True.
+
+    Returns:
+        list of ``DemographicModel`` (one per particle), rates per base pair.
+    """
+    seed = options.get("key", 1)
+    if not isinstance(seed, (int, np.integer)):
+        seed = int(np.asarray(seed).ravel()[-1])
+    rng = np.random.default_rng(seed)
+    niter = options.get("niter", 1000)
+    window_size = options.get("window_size", 100)
+    overlap = options.get("overlap", 500)
+    chunk_size = options.get("chunk_size")
+    max_samples = options.get("max_samples", 20)
+    num_workers = options.get("num_workers")
+    afs, chunks = init_mcmc_data(data, window_size, overlap, chunk_size, max_samples, num_workers)
+    del data
+    mutation_rate = options.get("mutation_rate")
+    if options.get("truth"):
+        if mutation_rate:
+            raise ValueError("mutation rate is already known from truth")
+        mutation_rate = options["truth"].theta
+    elpd_cutoff = options.get("elpd_cutoff", 100)
+    if options.get("afs_transform") is not None:
+        afs_transform = options["afs_transform"]
+    else:
+        # default: fold, then Bhaskar-Wang-Song 90% binning (mcmc.py:110-114)
+        T1 = fold_transform(len(afs) + 1)
+        T2 = bws_transform(T1 @ afs)
+        afs_transform = T2 @ T1
+
+    S = options.get("minibatch_size")
+    if not S:
+        S = max(1, min(5, int(len(chunks) / niter)))  # mcmc.py:119-121
+    if len(chunks) > 5 * S * niter:  # mcmc.py:126-139
+        chunks = rng.choice(chunks, size=(5 * S * niter,), replace=False)
+    N = len(chunks)
+
+    init = options.get("init")
+    ch0 = chunks[:, overlap:]
+    watterson = ch0[ch0 > -1].mean() / window_size  # mcmc.py:145-146
+    watterson = options.get("theta", watterson)
+    theta = watterson
+    if init is None:
+        if mutation_rate is not None:
+            N0 = theta / mutation_rate
+            options.setdefault("t1", 1e1 / 2 / N0)
+            options.setdefault("tM", 1e6 / 2 / N0)
+        t1 = options.get("t1", 1e-4)
+        tM = options.get("tM", 15.0)
+        rho = options.get("rho_over_theta", 1.0) * theta
+        pat = "14*1+1*2"  # mcmc.py:166
+        init = MCMCParams.from_linear(
+            pattern=pat, rho=rho * window_size, t1=t1, tM=tM, c=np.ones(len(Pattern(pat))),
+            theta=theta * window_size, alpha=options.get("alpha", 0.0), beta=options.get("beta", 0.0),
+        )
+    assert isinstance(init, MCMCParams)
+    lr = options.get("learning_rate", 0.1)
+    M = init.M
+
+    # particles ~ N(x0, sigma * I)  (mcmc.py:182-195: sigma multiplies the identity COVARIANCE)
+    x0 = init.flat.to(F64)
+    ndim = x0.shape[0]
+    num_particles = options.get("num_particles", 500)
+    noise = rng.standard_normal(size=(num_particles, ndim)) * np.sqrt(options.get("sigma", 1.0))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = (x0[None] + torch.as_tensor(noise, dtype=F64)).to(dev)
+    template = MCMCParams(pattern=init.pattern, t_tr=None, c_tr=None, rho_over_theta_tr=None,
+                          theta=init.theta, alpha=init.alpha, beta=init.beta)
+    state = svgd.init(x)
+
+    # this rank's rows of the chunk matrix; the warm-up columns stay attached (fused, see module doc)
+    rank, size = parallel.world()
+    # the reference asserts that no row of the scored part is entirely missing (gpu.py:111-113 on
+    # data_chunks, mcmc.py:203-209)
+    assert np.all(chunks[:, overlap:].max(axis=1) > -1), "data contains observations with all missing values"
+    mine = parallel.local_rows(N, rank, size)
+    train_kern = get_kernel(M=M, data=np.ascontiguousarray(chunks[mine]),
+                            double_precision=options.get("double_precision", False), overlap=overlap)
+
+    elpd = None
+    if test_data:
+        d = test_data.get_data(window_size)
+        test_afs = d["afs"]
+        test_rows = np.asarray(d["het_matrix"])[:max_samples]
+        N_test = test_rows.shape[0]
+        # reference: warm-up = one all-missing column (mcmc.py:230-233) -> prepend it, overlap = 1
+        test_rows = np.concatenate([np.full((N_test, 1), -1, np.int8), test_rows.clip(-1, 1).astype(np.int8)], 1)
+        t_mine = parallel.local_rows(N_test, rank, size)
+        test_kern = get_kernel(M=M, data=np.ascontiguousarray(test_rows[t_mine]), double_precision=False, overlap=1) \
+            if len(t_mine) else None
+        c_elpd = torch.tensor([0.0, 1.0, 1.0], dtype=F64, device=dev)
+
+        def elpd(xs):
+            with torch.no_grad():
+                if test_kern is None:  # more ranks than test rows: contribute zeros to the all-reduce
+                    k_, li = train_kern, np.zeros(0, np.int64)
+                else:
+                    k_, li = test_kern, np.arange(len(t_mine))
+                return float(_log_density_population(xs, template, c_elpd, k_, li, test_afs, afs_transform).mean())
+
+    c_train = torch.tensor([1.0, N / S, 1.0], dtype=F64, device=dev)  # mcmc.py:240-247
+
+    cb = options.get("callback") or (lambda *a, **k: None)
+
+    def dms(xs) -> DemographicModel:
+        dm = template.from_flat(xs.detach()).to_dm()
+        # rates are per window: scale to per base pair (mcmc.py:263-264)
+        dm = DemographicModel(eta=dm.eta, theta=dm.theta / window_size, rho=dm.rho / window_size)
+        if mutation_rate:
+            N1_N0 = (dm.theta / 2) / mutation_rate
+            dm = DemographicModel(eta=SizeHistory(t=dm.eta.t * N1_N0, c=dm.eta.c / N1_N0),
+                                  theta=mutation_rate, rho=dm.rho / N1_N0)
+        return dm
+
+    ema = best_elpd = None
+    it = range(niter)
+    if options.get("progress", True) and rank == 0:
+        try:
+            import tqdm.auto as tqdm
+
+            it = tqdm.trange(niter, desc="Fitting model")
+        except ImportError:
+            pass
+    for i in it:
+        inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
+        local = parallel.split_minibatch(inds, rank, size)
+        xs = state.particles.detach().requires_grad_(True)
+        lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
+        (g,) = torch.autograd.grad(lp.sum(), xs)
+        state = svgd.step(state, g, lr)
+        assert bool(torch.isfinite(state.particles).all())  # mcmc.py:281-285
+        if elpd is not None and i % 10 == 0:
+            e = elpd(state.particles)
+            ema = e if ema is None else 0.9 * ema + 0.1 * e
+            if best_elpd is None or ema > best_elpd[1]:
+                best_elpd = (i, ema)
+            if i - best_elpd[0] > elpd_cutoff:
+                break
+        cb(dms(state.particles))
+
+    out = dms(state.particles)
+    t, c = out.eta.t.cpu(), out.eta.c.cpu()
+    rho = out.rho.cpu() if isinstance(out.rho, torch.Tensor) else out.rho
+    th = out.theta
+    ret = []
+    for b in range(t.shape[0]):
+        ret.append(DemographicModel(eta=SizeHistory(t=t[b], c=c[b]),
+                                    theta=float(th[b]) if isinstance(th, torch.Tensor) and th.ndim else float(th),
+                                    rho=float(rho[b]) if isinstance(rho, torch.Tensor) and rho.ndim else float(rho)))
+    return ret

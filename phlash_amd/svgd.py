@@ -1,0 +1,75 @@
+"""Stein variational gradient descent with an AMSGrad update, on torch tensors.
+
+The reference delegates this to third-party code: ``blackjax.svgd(grad(log_density),
+optax.amsgrad(lr))`` (src/phlash/mcmc.py:178-199, 279; blackjax==1.2.5, optax==0.2.6 pinned in
+uv.lock).  Neither package is in the reference tree, and the only reference test that reaches them
+asserts types and lengths (tests/test_mcmc.py:10-32), so this restatement of their published
+algorithms is **parity unpinned** (SURVEY.md section 8a row A14): it is validated against analytic
+posteriors instead (tests/test_svgd.py).
+
+* kernel: RBF k(x, y) = exp(-|x-y|^2 / h); h starts at 1 and after every step is set to
+  median(pairwise distances)^2 / log(n) (blackjax ``update_median_heuristic``);
+* functional gradient fed to the optimiser as a loss gradient:
+  phi(x_j) = mean_i [ -k(x_i, x_j) grad log p(x_i) - grad_{x_i} k(x_i, x_j) ];
+* optax.amsgrad: b1 = 0.9, b2 = 0.999, eps = 1e-8, bias-corrected moments, running max of the
+  corrected second moment, update = -lr * m_hat / (sqrt(v_max) + eps).
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import torch
+
+
+@dataclasses.dataclass
+class SVGDState:
+    particles: torch.Tensor  # [n, D]
+    length_scale: float
+    mu: torch.Tensor
+    nu: torch.Tensor
+    nu_max: torch.Tensor
+    count: int
+
+
+def init(particles: torch.Tensor) -> SVGDState:
+    z = torch.zeros_like(particles)
+    return SVGDState(particles=particles, length_scale=1.0, mu=z, nu=z.clone(), nu_max=z.clone(), count=0)
+
+
+def functional_gradient(x: torch.Tensor, grad_logp: torch.Tensor, h: float) -> torch.Tensor:
+    """phi [n, D] as defined in the module docstring."""
+    n = x.shape[0]
+    diff = x[:, None, :] - x[None, :, :]  # [i, j] = x_i - x_j
+    k = torch.exp(-(diff**2).sum(-1) / h)  # [i, j]
+    grad_k_i = (-2.0 / h) * diff * k[..., None]  # d k(x_i, x_j) / d x_i
+    return (-(k.T @ grad_logp) - grad_k_i.sum(0)) / n
+
+
+def median_heuristic(x: torch.Tensor) -> float:
+    n = x.shape[0]
+    if n < 2:
+        return 1.0
+    d = torch.cdist(x, x)
+    iu = torch.tril_indices(n, n, offset=-1, device=x.device)
+    med = torch.quantile(d[iu[0], iu[1]], 0.5)
+    return float(med**2 / math.log(n))
+
+
+def amsgrad_update(state: SVGDState, g: torch.Tensor, lr: float, b1=0.9, b2=0.999, eps=1e-8):
+    count = state.count + 1
+    mu = b1 * state.mu + (1 - b1) * g
+    nu = b2 * state.nu + (1 - b2) * g * g
+    mu_hat = mu / (1 - b1**count)
+    nu_hat = nu / (1 - b2**count)
+    nu_max = torch.maximum(state.nu_max, nu_hat)
+    upd = -lr * mu_hat / (torch.sqrt(nu_max) + eps)
+    return upd, mu, nu, nu_max, count
+
+
+def step(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:
+    phi = functional_gradient(state.particles, grad_logp, state.length_scale)
+    upd, mu, nu, nu_max, count = amsgrad_update(state, phi, lr)
+    x = state.particles + upd
+    return SVGDState(particles=x, length_scale=median_heuristic(x), mu=mu, nu=nu, nu_max=nu_max, count=count)

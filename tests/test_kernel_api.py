@@ -1,0 +1,191 @@
+"""GPU tests of the drop-in surface: the reference's own kernel tests (tests/test_gpu.py,
+tests/test_model.py, tests/test_mcmc.py) re-expressed against ``phlash_amd`` with the CPU oracle
+in the role the pure-JAX path plays there."""
+
+import numpy as np
+import pytest
+
+from oracle import cport
+from oracle import psmc_numpy as o
+from oracle import psmc_torch as ot
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+F64 = torch.float64
+
+
+@pytest.fixture
+def dm():
+    from phlash_amd.size_history import DemographicModel
+
+    return DemographicModel.default(pattern="16*1", theta=1e-2, rho=1e-2)
+
+
+@pytest.fixture
+def pp(dm):
+    from phlash_amd.params import PSMCParams
+
+    return PSMCParams.from_dm(dm)
+
+
+@pytest.fixture
+def kern(data):
+    from phlash_amd.kernel import get_kernel
+
+    return get_kernel(M=16, data=data, double_precision=True)
+
+
+def _oracle_pp(pp):
+    return o.PP(*(np.asarray(a.detach().cpu()) for a in pp))
+
+
+# reference tests/test_gpu.py:34-40
+def test_eq_grad_nograd(pp, data, kern):
+    inds = np.arange(len(data))
+    ppn = type(pp)(*(a.numpy() for a in pp))
+    ll1, dll = kern(ppn, inds, grad=True)
+    ll2 = kern(ppn, inds, grad=False)
+    assert isinstance(ll1, np.ndarray) and ll1.dtype == np.float64 and ll1.shape == (10,)
+    np.testing.assert_allclose(ll1, ll2)
+    assert dll.b.shape == (10, 16) and dll.b.dtype == kern.float_type
+    # the operator returns d ll / d log(param)  (gpu.py:647-653, 686-691)
+    _, g = cport.batch(np.stack(ppn, -2)[None, None], data, inds, 0)
+    np.testing.assert_allclose(np.stack(dll, -2), g[0] * np.stack(ppn, -2)[None], rtol=1e-7, atol=1e-9)
+
+
+def test_call_shapes(pp, data, kern):
+    ppn = type(pp)(*(a.numpy() for a in pp))
+    ll, dll = kern(ppn, np.int64(3), grad=True)  # scalar index, [M] params -> scalars / [M]
+    assert ll.shape == () and dll.d.shape == (16,)
+    per_chunk = type(pp)(*(np.repeat(a[None], 4, 0) for a in ppn))
+    ll, dll = kern(per_chunk, np.array([0, 1, 2, 3]), grad=True)  # [S, M]
+    assert ll.shape == (4,) and dll.pi.shape == (4, 16)
+    full = type(pp)(*(np.repeat(a[None, None], 3, 0).repeat(4, 1) for a in ppn))
+    ll = kern(full, np.array([0, 1, 2, 3]), grad=False)  # [B, S, M]
+    assert ll.shape == (3, 4)
+    with pytest.raises(AssertionError):
+        kern(ppn, np.array([0, 10]), grad=False)  # index out of range (gpu.py:197-199)
+    bad = ppn._replace(d=np.full(16, np.nan))
+    with pytest.raises(AssertionError):
+        kern(bad, np.array([0]), grad=False)  # non-finite parameters (gpu.py:214)
+
+
+# reference tests/test_gpu.py:43-55 and tests/test_model.py:8-11
+def test_pyll_vs_hip(dm, data, missing_data, pp):
+    from phlash_amd.kernel import get_kernel
+
+    for d in (data, missing_data):
+        kern = get_kernel(M=16, data=d, double_precision=True)
+        ll1 = float(kern.loglik(dm, 0))
+        ll2 = o.psmc_ll(_oracle_pp(pp), d[0])[1]
+        np.testing.assert_allclose(ll1, ll2, rtol=1e-10)
+        k32 = get_kernel(M=16, data=d, double_precision=False)
+        np.testing.assert_allclose(float(k32.loglik(dm, 0)), ll2, rtol=1e-5)
+
+
+# reference tests/test_gpu.py:58-64 and tests/test_model.py:14-19: value and gradient w.r.t. the
+# demographic model, kernel path vs AD through the plain recursion
+def test_value_and_grad_wrt_dm(data, kern):
+    from phlash_amd.size_history import DemographicModel, SizeHistory
+
+    base = DemographicModel.default("16*1", 1e-2, 1e-2)
+    t = base.eta.t.clone().requires_grad_(True)
+    c = base.eta.c.clone().requires_grad_(True)
+    theta = torch.tensor(1e-2, dtype=F64, requires_grad=True)
+    rho = torch.tensor(1e-2, dtype=F64, requires_grad=True)
+    ll1 = kern.loglik(DemographicModel(SizeHistory(t, c), theta, rho), 0)
+    g1 = torch.autograd.grad(ll1, [t, c, theta, rho])
+    t2, c2 = t.detach().clone().requires_grad_(True), c.detach().clone().requires_grad_(True)
+    th2, rh2 = theta.detach().clone().requires_grad_(True), rho.detach().clone().requires_grad_(True)
+    ll2 = ot.psmc_ll(ot.from_dm(t2, c2, th2, rh2), data[0])
+    g2 = torch.autograd.grad(ll2, [t2, c2, th2, rh2])
+    np.testing.assert_allclose(float(ll1), float(ll2), atol=1e-8, rtol=1e-5)
+    for x, y in zip(g1, g2):
+        np.testing.assert_allclose(x.cpu(), y, atol=1e-8, rtol=1e-5)
+
+
+# reference tests/test_gpu.py:27-31: finite differences w.r.t. the model
+def test_check_grads(kern):
+    from phlash_amd.size_history import DemographicModel, SizeHistory
+
+    base = DemographicModel.default("16*1", 1e-2, 1e-2)
+    c = base.eta.c.clone().requires_grad_(True)
+    ll = kern.loglik(DemographicModel(SizeHistory(base.eta.t, c), 1e-2, 1e-2), 0)
+    (g,) = torch.autograd.grad(ll, c)
+    for k in (0, 5, 15):
+        h = 1e-5
+        cp, cm = base.eta.c.clone(), base.eta.c.clone()
+        cp[k] += h
+        cm[k] -= h
+        fd = (float(kern.loglik(DemographicModel(SizeHistory(base.eta.t, cp), 1e-2, 1e-2), 0))
+              - float(kern.loglik(DemographicModel(SizeHistory(base.eta.t, cm), 1e-2, 1e-2), 0))) / (2 * h)
+        np.testing.assert_allclose(float(g[k]), fd, rtol=1e-2, atol=1e-6)
+
+
+def test_log_density_fused_and_two_step(rng):
+    """log_density (model.py:24-73): fused warm-up kernel == reference-style two-step call ==
+    oracle's two-step evaluation, for a batch of particles."""
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.model import log_density
+    from phlash_amd.params import MCMCParams
+
+    W, L = 50, 400
+    chunks = (rng.uniform(size=(6, W + L)) < 0.06).astype(np.int8)
+    pat = "14*1+1*2"
+    init = MCMCParams.from_linear(pat, 1e-4, 15.0, np.ones(15), 1e-2, 1e-2, alpha=0.1, beta=0.01)
+    X = init.flat[None] + 0.2 * torch.tensor(rng.normal(size=(3, 18)))
+    inds = np.array([4, 0, 4])
+    c = [1.0, 2.0, 1.0]
+    want = np.array([o.log_prior(x.numpy(), pat, 0.1, 0.01) + 2.0 * o.hmm_term(x.numpy(), pat, 1e-2, chunks, inds, W) for x in X])
+    fused = get_kernel(16, chunks, True, overlap=W)
+    v1 = log_density(init.from_flat(X), c, inds, None, fused, afs=np.ones(1))
+    np.testing.assert_allclose(v1.cpu(), want, rtol=1e-9)
+    plain = get_kernel(16, np.ascontiguousarray(chunks[:, W:]), True)
+    plain.host_data = np.ascontiguousarray(chunks[:, W:])
+    v2 = log_density(init.from_flat(X), c, inds, chunks[inds][:, :W], plain, afs=np.ones(1))
+    np.testing.assert_allclose(v2.cpu(), want, rtol=1e-9)
+    # gradient w.r.t. the particles through the kernel == autograd through the oracle's recursion
+    Xg = X.clone().requires_grad_(True)
+    (g,) = torch.autograd.grad(log_density(init.from_flat(Xg), [0.0, 1.0, 0.0], inds, None, fused).sum(), Xg)
+    x0 = X[1].clone().requires_grad_(True)
+    tot = sum(ot.psmc_ll(ot.particle_to_params(x0, pat, 1e-2), chunks[i], W) for i in inds)
+    (g0,) = torch.autograd.grad(tot, x0)
+    np.testing.assert_allclose(g[1], g0, rtol=1e-6, atol=1e-8)
+
+
+# reference tests/test_mcmc.py:21-32
+def test_functional2():
+    import phlash_amd
+    from phlash_amd.data import RawContig
+    from phlash_amd.size_history import DemographicModel
+
+    het = np.array([[0, 1, 0, 1, 1]], dtype=np.int8)
+    ctg = RawContig(het, np.array([1]), 100)
+    res = phlash_amd.fit([ctg], niter=2, num_particles=5, chunk_size=1, overlap=1, progress=False)
+    assert isinstance(res, list) and len(res) == 5
+    assert isinstance(res[0], DemographicModel)
+
+
+def test_psmc(psmcfa_file):
+    import phlash_amd
+
+    res = phlash_amd.psmc([psmcfa_file] * 3, niter=2, num_particles=5, chunk_size=1, overlap=1, progress=False)
+    assert len(res) == 5
+
+
+def test_fit_moves_toward_truth():
+    """A short fit on data simulated from a 2x-larger population must raise the log density of the
+    particle population (sanity of the whole inner step; statistical parity with the reference's
+    sampler is unpinned -- see svgd.py)."""
+    import phlash_amd
+    from phlash_amd.data import RawContig
+    from phlash_amd.synth import simulate_chunks
+
+    het = simulate_chunks(16, 4, 20000, seed=5, theta=2e-2, rho=1e-2)
+    ctgs = [RawContig(h[None], np.array([1]), 100) for h in het]
+    seen = []
+    res = phlash_amd.fit(ctgs, test_data=ctgs[0], niter=30, num_particles=16, chunk_size=2000, overlap=100,
+                         minibatch_size=8, progress=False, callback=lambda dm: seen.append(float(dm.eta.c.mean())))
+    assert len(res) == 16 and len(seen) == 30
+    assert all(np.isfinite(seen))

@@ -1,0 +1,77 @@
+"""Repository contracts: the C-ABI library loads and exports every symbol include/phlash_hip.h
+declares (no compute calls -- there is no GPU here), the product never imports the oracle, and the
+product fails loudly instead of falling back when the GPU / library is missing."""
+
+import ast
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ensure_built():
+    from phlash_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib
+
+
+def test_abi_exports_every_declared_symbol():
+    _lib = _ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "phlash_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(phk_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.phk_version() >= 1000
+    assert loaded.phk_last_error() == b""
+    # argument checking that needs no GPU
+    assert loaded.phk_set_variant(None, 0, 0) == _lib.PHK_EINVAL
+    assert b"NULL" in loaded.phk_last_error()
+    h = ctypes.c_void_p()
+    assert loaded.phk_create(ctypes.byref(h), 7, None, 1, 1, 0, 0, 0) == _lib.PHK_EUNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.PHK_EUNSUPPORTED)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "phlash_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                for n in names:
+                    assert not n.split(".")[0] == "oracle", f"{f} imports {n}"
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        if f.endswith((".hip", ".h", ".cpp")):
+            assert "oracle" not in open(os.path.join(pkg, "csrc", f)).read()
+
+
+def test_no_fallback_without_gpu():
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _ensure_built()
+    from phlash_amd.kernel import get_kernel
+
+    data = np.zeros((2, 10), dtype=np.int8)
+    with pytest.raises((RuntimeError, ImportError)):
+        get_kernel(16, data, False)
