@@ -62,14 +62,15 @@ def cpu_baseline(P, data, overlap, chunk_size, target_s, ll_gpu):
 
     cores = os.cpu_count() or 1
     nthreads = min(cores, cport.max_threads())
-    B = min(4, P.shape[0])
-    # probe, then size the sample for ~target_s seconds
+    B = P.shape[0]
+    # probe with enough sequences to occupy every thread, then size the sample for ~target_s seconds
+    S0 = int(min(data.shape[0], max(2, -(-2 * nthreads // B))))
     t0 = time.perf_counter()
-    cport.batch(P[:B], data, np.arange(2), overlap, nthreads=nthreads)
-    rate = B * 2 * chunk_size / (time.perf_counter() - t0)
-    S = int(max(2, min(data.shape[0], target_s * rate / (B * chunk_size))))
+    cport.batch(P, data, np.arange(S0), overlap, nthreads=nthreads)
+    rate = B * S0 * chunk_size / (time.perf_counter() - t0)
+    S = int(max(S0, min(data.shape[0], target_s * rate / (B * chunk_size))))
     t0 = time.perf_counter()
-    ll, _ = cport.batch(P[:B], data, np.arange(S), overlap, nthreads=nthreads)
+    ll, _ = cport.batch(P, data, np.arange(S), overlap, nthreads=nthreads)
     dt = time.perf_counter() - t0
     rel = np.abs(ll_gpu[:B, :S] - ll) / np.abs(ll)
     return {
@@ -214,8 +215,9 @@ def main():
             with torch.no_grad():
                 mcp = template.from_flat(x0.to(dev))
                 pp0 = PSMCParams.from_dm(mcp.to_dm())
-                ll_gpu, _ = kern.value_and_grad(PSMCParams(*(f[:4] for f in pp0)), inds, reduce_chunks=False)
-            P = pp0.stack().cpu().numpy()[:, None]
+                nb = min(B, 16)  # bounded sample of the particles for the CPU leg
+                ll_gpu, _ = kern.value_and_grad(PSMCParams(*(f[:nb] for f in pp0)), inds, reduce_chunks=False)
+            P = pp0.stack().cpu().numpy()[:nb, None]
             cb, rel = cpu_baseline(P, data, W, L, a.cpu_seconds, ll_gpu.cpu().numpy())
             out["cpu_baseline"] = cb
             out["parity"] = {"max_rel_err_loglik_vs_f64_oracle": rel, "bar": 1e-5,

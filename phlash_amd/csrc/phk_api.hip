@@ -105,14 +105,15 @@ void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T) {
     int r = h->force_R, t = h->force_T;
     if (!t) t = 8;
     if (!r) {
-        // smallest R (fewest cross-lane steps) that still puts >= 2 waves on each of the 1024 SIMDs;
-        // otherwise the largest valid R.
+        // smallest R (fewest cross-lane steps, fewest instructions per site.particle) that still
+        // gives every one of the 1024 SIMDs a wave; otherwise the largest valid R.  Measured at
+        // cfg2 (50,000 sequences, K=16, f32): R=2 3.6e10, R=1 3.2e10, R=4 2.8e10 site.particle/s.
         int best = 0;
         for (int c = 1; c <= 16; c <<= 1) {
             if (!valid_R(h->K, c)) continue;
             if (bwd_threads(h, c, t) == 0) continue;
             best = c;
-            if (nseq * c / 64 >= 2048) break;
+            if (nseq * c / 64 >= 1024) break;
         }
         r = best ? best : 1;
     }

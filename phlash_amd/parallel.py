@@ -73,7 +73,10 @@ def sharded_loglik_sum(kern, pp, local_inds) -> torch.Tensor:
     params = pp.stack().to(kern.device)
 
     def evaluate(p, inds):
-        inds = torch.as_tensor(np.asarray(inds), dtype=torch.int64, device=kern.device)
+        if isinstance(inds, torch.Tensor):
+            inds = inds.to(device=kern.device, dtype=torch.int64)
+        else:
+            inds = torch.as_tensor(np.asarray(inds), dtype=torch.int64, device=kern.device)
         if inds.numel() == 0:
             z = torch.zeros(p.shape[0], dtype=torch.float64, device=kern.device)
             return z, torch.zeros(p.shape, dtype=torch.float64, device=kern.device)

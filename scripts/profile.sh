@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of the bench command.
+# Usage: scripts/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
+# Counters are collected in their own passes, never together with tracing domains.
+set -u
+TAG=${1:-r01}; shift || true
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_$C.log" 2>&1
+done
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_SQ" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_SQ2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ2.log" 2>&1
+cd "$REPO"
+python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+# keep only the small files for the merge back (<= 64 MiB)
+find "$OUT" -name "*.db" -delete
+find "$OUT" -size +8M -delete
+cat "$OUT/summary.txt"
