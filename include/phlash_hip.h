@@ -77,10 +77,16 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
                int grad_dlog, void* stream);
 
 /* Tuning / introspection (no reference counterpart).
- * R = lanes per sequence (1,2,4,8,16; must divide K, K/R <= 16), T = checkpoint block (8 or 16).
+ * R = lanes per sequence (1,2,4,8,16; must divide K, K/R <= 16), T = checkpoint block (8, or 16
+ * where K/R <= 4).
  * 0 = choose automatically from B*S. */
 int phk_set_variant(phk_handle* h, int R, int T);
 int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T);
+/* The scaled forward state is brought back to [0.5,1) by an exact power of two after every nrm-th
+ * site (1, 2 or 4; 0 = library default).  nrm = 1 is the reference's per-site normalisation
+ * (hmm.py:77-79); larger intervals do the same arithmetic with fewer rescales and are safe while
+ * nrm consecutive sites cannot shrink the total mass below the float range. */
+int phk_set_rescale_interval(phk_handle* h, int nrm);
 /* Upper bound for the checkpoint workspace; larger problems are run in particle / chunk slabs. */
 int phk_set_workspace_limit(phk_handle* h, int64_t bytes);
 int64_t phk_workspace_bytes(phk_handle* h);

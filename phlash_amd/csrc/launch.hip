@@ -15,69 +15,90 @@ namespace phk {
 using real_t = PHK_REAL;
 constexpr int KK = PHK_K;
 
-template <int R, int T>
-static hipError_t fwd_rt(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
+static size_t lds_bytes(int R, int nt) {
+    const int spl = KK / R;
+    return (size_t)3 * (2 * ((spl + 1) / 2)) * nt * sizeof(real_t);  // per-thread emission table
+}
+
+template <int R, int T, int NRM>
+static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     const int64_t nseq = a.B * a.S;
     const int spb = nt / R;  // sequences per workgroup
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
+    const size_t lds = lds_bytes(R, nt);
     if (ckpt)
-        hipLaunchKernelGGL((fwd_kernel<real_t, KK, R, T, true>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((fwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL((fwd_kernel<real_t, KK, R, T, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((fwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds, st, a);
     return hipGetLastError();
 }
 
-template <int R, int T>
-static hipError_t bwd_rt(const KArgs& a, int nt, hipStream_t st) {
+template <int R, int T, int NRM>
+static hipError_t bwd_rtn(const KArgs& a, int nt, hipStream_t st) {
     const int64_t nseq = a.B * a.S;
     const int spb = nt / R;
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
-    const size_t lds = (size_t)T * (KK / R + 1) * nt * sizeof(real_t);
-    auto kern = bwd_kernel<real_t, KK, R, T>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM>), grid, block, lds_bytes(R, nt), st, a);
     return hipGetLastError();
 }
 
-template <int R>
-static hipError_t fwd_r(int T, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
-    if constexpr (KK % R != 0 || KK / R > 16 || R > KK) {
+// T = 16 keeps 17 alpha vectors in registers: only offered where a lane owns <= 4 states
+template <int R, int T>
+constexpr bool variant_ok() { return KK % R == 0 && KK / R <= 16 && R <= KK && (T == 8 || KK / R <= 4); }
+
+template <int R, int T>
+static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
+    if constexpr (!variant_ok<R, T>()) {
         return hipErrorInvalidValue;
     } else {
-        if (T == 8) return fwd_rt<R, 8>(ckpt, a, nt, st);
-        if (T == 16) return fwd_rt<R, 16>(ckpt, a, nt, st);
+        if (nrm == 1) return fwd_rtn<R, T, 1>(ckpt, a, nt, st);
+        if (nrm == 2) return fwd_rtn<R, T, 2>(ckpt, a, nt, st);
+        if (nrm == 4) return fwd_rtn<R, T, 4>(ckpt, a, nt, st);
         return hipErrorInvalidValue;
     }
 }
-template <int R>
-static hipError_t bwd_r(int T, const KArgs& a, int nt, hipStream_t st) {
-    if constexpr (KK % R != 0 || KK / R > 16 || R > KK) {
+template <int R, int T>
+static hipError_t bwd_rt(int nrm, const KArgs& a, int nt, hipStream_t st) {
+    if constexpr (!variant_ok<R, T>()) {
         return hipErrorInvalidValue;
     } else {
-        if (T == 8) return bwd_rt<R, 8>(a, nt, st);
-        if (T == 16) return bwd_rt<R, 16>(a, nt, st);
+        if (nrm == 1) return bwd_rtn<R, T, 1>(a, nt, st);
+        if (nrm == 2) return bwd_rtn<R, T, 2>(a, nt, st);
+        if (nrm == 4) return bwd_rtn<R, T, 4>(a, nt, st);
         return hipErrorInvalidValue;
     }
 }
 
-hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
+template <int R>
+static hipError_t fwd_r(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
+    if (T == 8) return fwd_rt<R, 8>(nrm, ckpt, a, nt, st);
+    if (T == 16) return fwd_rt<R, 16>(nrm, ckpt, a, nt, st);
+    return hipErrorInvalidValue;
+}
+template <int R>
+static hipError_t bwd_r(int T, int nrm, const KArgs& a, int nt, hipStream_t st) {
+    if (T == 8) return bwd_rt<R, 8>(nrm, a, nt, st);
+    if (T == 16) return bwd_rt<R, 16>(nrm, a, nt, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     switch (R) {
-        case 1: return fwd_r<1>(T, ckpt, a, nt, st);
-        case 2: return fwd_r<2>(T, ckpt, a, nt, st);
-        case 4: return fwd_r<4>(T, ckpt, a, nt, st);
-        case 8: return fwd_r<8>(T, ckpt, a, nt, st);
-        case 16: return fwd_r<16>(T, ckpt, a, nt, st);
+        case 1: return fwd_r<1>(T, nrm, ckpt, a, nt, st);
+        case 2: return fwd_r<2>(T, nrm, ckpt, a, nt, st);
+        case 4: return fwd_r<4>(T, nrm, ckpt, a, nt, st);
+        case 8: return fwd_r<8>(T, nrm, ckpt, a, nt, st);
+        case 16: return fwd_r<16>(T, nrm, ckpt, a, nt, st);
     }
     return hipErrorInvalidValue;
 }
-hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, const KArgs& a, int nt, hipStream_t st) {
+hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, int nrm, const KArgs& a, int nt, hipStream_t st) {
     switch (R) {
-        case 1: return bwd_r<1>(T, a, nt, st);
-        case 2: return bwd_r<2>(T, a, nt, st);
-        case 4: return bwd_r<4>(T, a, nt, st);
-        case 8: return bwd_r<8>(T, a, nt, st);
-        case 16: return bwd_r<16>(T, a, nt, st);
+        case 1: return bwd_r<1>(T, nrm, a, nt, st);
+        case 2: return bwd_r<2>(T, nrm, a, nt, st);
+        case 4: return bwd_r<4>(T, nrm, a, nt, st);
+        case 8: return bwd_r<8>(T, nrm, a, nt, st);
+        case 16: return bwd_r<16>(T, nrm, a, nt, st);
     }
     return hipErrorInvalidValue;
 }

@@ -17,8 +17,8 @@
 
 namespace phk {
 #define PHK_DECL(tag)                                                                                 \
-    hipError_t launch_fwd_##tag(int R, int T, bool ckpt, const KArgs& a, int nt, hipStream_t st);     \
-    hipError_t launch_bwd_##tag(int R, int T, const KArgs& a, int nt, hipStream_t st);
+    hipError_t launch_fwd_##tag(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st); \
+    hipError_t launch_bwd_##tag(int R, int T, int nrm, const KArgs& a, int nt, hipStream_t st);
 PHK_DECL(f32_4) PHK_DECL(f32_8) PHK_DECL(f32_16) PHK_DECL(f32_32) PHK_DECL(f32_64)
 PHK_DECL(f64_4) PHK_DECL(f64_8) PHK_DECL(f64_16) PHK_DECL(f64_32) PHK_DECL(f64_64)
 #undef PHK_DECL
@@ -44,7 +44,7 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                            \
     } while (0)
 
-constexpr size_t LDS_BYTES = 160 * 1024;
+constexpr int DEFAULT_NRM = 2;  // rescale every 2nd site unless told otherwise
 
 struct DevBuf {
     void* p = nullptr;
@@ -80,7 +80,7 @@ struct phk_handle {
     uint32_t* packed = nullptr;
     DevBuf ckpt, aux, gacc;
     int64_t ws_limit = 0;
-    int force_R = 0, force_T = 0;
+    int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int profiling = 0;
     std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch pair of the last call
     int n_launches = 0;
@@ -92,14 +92,8 @@ bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R
 
 size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
 
-// threads per workgroup for the backward kernel: as many waves (<= 4) as the LDS block store allows
-int bwd_threads(const phk_handle* h, int R, int T) {
-    const size_t per_thread = (size_t)T * (h->K / R + 1) * real_size(h);
-    int nt = 256;
-    while (nt > 64 && per_thread * nt > LDS_BYTES / 2) nt >>= 1;  // prefer >= 2 workgroups per CU
-    while (nt > 64 && per_thread * nt > LDS_BYTES) nt >>= 1;
-    return per_thread * nt <= LDS_BYTES ? nt : 0;
-}
+// T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
+bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
 
 void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T) {
     int r = h->force_R, t = h->force_T;
@@ -111,7 +105,7 @@ void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T) {
         int best = 0;
         for (int c = 1; c <= 16; c <<= 1) {
             if (!valid_R(h->K, c)) continue;
-            if (bwd_threads(h, c, t) == 0) continue;
+            if (!valid_T(h->K, c, t)) continue;
             best = c;
             if (nseq * c / 64 >= 1024) break;
         }
@@ -121,8 +115,8 @@ void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T) {
     *T = t;
 }
 
-typedef hipError_t (*fwd_fn)(int, int, bool, const phk::KArgs&, int, hipStream_t);
-typedef hipError_t (*bwd_fn)(int, int, const phk::KArgs&, int, hipStream_t);
+typedef hipError_t (*fwd_fn)(int, int, int, bool, const phk::KArgs&, int, hipStream_t);
+typedef hipError_t (*bwd_fn)(int, int, int, const phk::KArgs&, int, hipStream_t);
 
 bool pick_launchers(const phk_handle* h, fwd_fn* f, bwd_fn* b) {
 #define PHK_CASE(k)                                                        \
@@ -232,9 +226,17 @@ int phk_set_variant(phk_handle* h, int R, int T) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (R != 0 && !valid_R(h->K, R)) return fail(PHK_EINVAL, "R=%d invalid for K=%d", R, h->K);
     if (T != 0 && T != 8 && T != 16) return fail(PHK_EINVAL, "T must be 0, 8 or 16");
-    if (R != 0 && bwd_threads(h, R, T ? T : 8) == 0) return fail(PHK_EINVAL, "R=%d T=%d does not fit the LDS", R, T);
+    if (R != 0 && !valid_T(h->K, R, T ? T : 8)) return fail(PHK_EINVAL, "R=%d T=%d not available (T=16 needs K/R <= 4)", R, T);
     h->force_R = R;
     h->force_T = T;
+    return PHK_OK;
+}
+
+int phk_set_rescale_interval(phk_handle* h, int nrm) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (nrm == 0) nrm = DEFAULT_NRM;
+    if (nrm != 1 && nrm != 2 && nrm != 4) return fail(PHK_EINVAL, "rescale interval must be 1, 2 or 4 (0 = default)");
+    h->nrm = nrm;
     return PHK_OK;
 }
 
@@ -296,9 +298,8 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     int R = 1, T = 8;
     choose_variant(h, B * S, &R, &T);
     if (!valid_R(K, R)) return fail(PHK_EINVAL, "no valid lanes-per-sequence for K=%d", K);
-    const int nt_b = bwd_threads(h, R, T);
-    if (want_grad && nt_b == 0) return fail(PHK_EUNSUPPORTED, "R=%d T=%d does not fit the LDS", R, T);
-    const int nt_f = 256;
+    if (!valid_T(K, R, T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, T, K);
+    const int nt_b = 256, nt_f = 256;
 
     // slab the (particle, chunk) grid so that the checkpoint store stays under the workspace limit
     const int64_t nblk = (h->L + T - 1) / T;
@@ -358,11 +359,11 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
                 e2 = h->ev[3 * h->n_launches + 2];
                 HIP_TRY(hipEventRecord(e0, st));
             }
-            hipError_t e = lf(R, T, want_grad, a, nt_f, st);
+            hipError_t e = lf(R, T, h->nrm, want_grad, a, nt_f, st);
             if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
             if (h->profiling) HIP_TRY(hipEventRecord(e1, st));
             if (want_grad) {
-                e = lb(R, T, a, nt_b, st);
+                e = lb(R, T, h->nrm, a, nt_b, st);
                 if (e != hipSuccess) return fail(PHK_EHIP, "backward kernel launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
             }
             if (h->profiling) {

@@ -17,14 +17,19 @@
 //     normaliser is a quad_perm / row_mirror butterfly.  No LDS or MFMA on that path.
 //   * the 7*K parameters of a sequence live in registers for the whole scan.
 //   * observations are re-packed on upload to 2 bits per site (16 sites per dword).
-//   * normalisation is by an exact power of two (v_frexp_exp / v_ldexp): the scaled state stays
-//     in [0.5,1) and the integer exponents are summed, so ll = E*ln2 + log(sum) takes one log per
+//   * normalisation is by an exact power of two (v_frexp_exp, multiply by 2^-e): the scaled state
+//     returns to [0.5,1) and the integer exponents are summed, so ll = E*ln2 + log(sum) takes one log per
 //     sequence and loses nothing to f32 accumulation of 60,000 log terms.
 //   * gradient: kernel 1 (forward) stores alpha every T sites to HBM (coalesced, K reals per
 //     sequence per block); kernel 2 walks the blocks backwards: re-runs the T forward sites of a
-//     block into LDS (alpha_{t-1} and the scale per site), then sweeps them in reverse
-//     accumulating the six parameter rows in registers (f32 partial sums are flushed to f64 every
-//     FLUSH_SITES sites).
+//     block keeping every alpha in REGISTERS (both site loops fully unrolled), then sweeps them in
+//     reverse accumulating the six parameter rows in registers (f32 partial sums are flushed to
+//     f64 every FLUSH_SITES sites).
+//   * the element-wise part of a site runs on packed pairs (v_pk_fma_f32 ...); the emission row of
+//     a site is fetched from a per-thread LDS table [hom, het, ones] with one ds_read per pair
+//     instead of two v_cndmask per state.
+//   * rescaling may be done every NRM-th site only (NRM in {1,2,4}); NRM = 1 is the reference's
+//     per-site normalisation.
 //
 // Numerics contract: every arithmetic step goes through explicit fma / mul / add in ONE inline
 // step function used by both kernels and the file is compiled with -ffp-contract=off, so the
@@ -118,136 +123,185 @@ struct Group {
 };
 
 // ---------------------------------------------------------------------------------------------
+// packed pairs: the element-wise part of every site step runs on 2-vectors so that the f32
+// instantiation issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one issue slot, two states).
+// A wave can issue one VALU instruction every 4 cycles; at the <= 2 waves per SIMD this problem
+// offers, halving the instruction count is worth more than anything else.
+// ---------------------------------------------------------------------------------------------
+template <typename real>
+using vec2 = real __attribute__((ext_vector_type(2)));
+
+template <typename real>
+__device__ __forceinline__ vec2<real> fma2(vec2<real> a, vec2<real> b, vec2<real> c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+template <typename real>
+__device__ __forceinline__ vec2<real> splat(real x) {
+    vec2<real> r = {x, x};
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-lane slice of one sequence's parameters + the forward / backward site steps
 // ---------------------------------------------------------------------------------------------
 template <typename real, int K, int R>
 struct Lane {
-    static constexpr int SPL = K / R;
+    static constexpr int SPL = K / R;        // states owned by this lane
+    static constexpr int NP = (SPL + 1) / 2;  // packed pairs (odd SPL: the last pair's .y is padding)
+    static constexpr int EROW = 2 * NP;       // reals per emission row in the LDS table
     static_assert(SPL * R == K, "R must divide K");
-    real b[SPL], d[SPL], u[SPL], v[SPL], e0[SPL], e1[SPL];
+    using V = vec2<real>;
+
+    V b[NP], d[NP], u[NP], v[NP];
+    const real* etab;  // LDS: this thread's emission rows [3][EROW]: hom, het, missing (= ones)
     Group<real, R> g;
 
-    // p: [7,K] rows b,d,u,v,emis0,emis1,pi (gpu.py:189 stacking order)
-    __device__ __forceinline__ void load(const real* __restrict__ p, int rank, real (&pi)[SPL]) {
+    static __device__ __forceinline__ real get(const V (&x)[NP], int i) { return x[i >> 1][i & 1]; }
+
+    // p: [7,K] rows b,d,u,v,emis0,emis1,pi (gpu.py:189 stacking order); padding lanes hold zeros
+    // (ones in the emission rows) so that they stay exactly 0 through every step.
+    __device__ __forceinline__ void load(const real* __restrict__ p, int rank, real* etab_thread, V (&pi)[NP]) {
         g.init(rank);
+        etab = etab_thread;
         const real* q = p + rank * SPL;
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            b[i] = q[0 * K + i];
-            d[i] = q[1 * K + i];
-            u[i] = q[2 * K + i];
-            v[i] = q[3 * K + i];
-            e0[i] = q[4 * K + i];
-            e1[i] = q[5 * K + i];
-            pi[i] = q[6 * K + i];
+        for (int h = 0; h < NP; ++h) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int i = 2 * h + c;
+                const bool ok = i < SPL;
+                b[h][c] = ok ? q[0 * K + i] : real(0);
+                d[h][c] = ok ? q[1 * K + i] : real(0);
+                u[h][c] = ok ? q[2 * K + i] : real(0);
+                v[h][c] = ok ? q[3 * K + i] : real(0);
+                pi[h][c] = ok ? q[6 * K + i] : real(0);
+                etab_thread[0 * EROW + i] = ok ? q[4 * K + i] : real(1);
+                etab_thread[1 * EROW + i] = ok ? q[5 * K + i] : real(1);
+                etab_thread[2 * EROW + i] = real(1);
+            }
         }
+    }
+
+    __device__ __forceinline__ void emis(int code, V (&e)[NP]) const {
+        const V* row = (const V*)(etab + code * EROW);
+#pragma unroll
+        for (int h = 0; h < NP; ++h) e[h] = row[h];
     }
 
     // exclusive prefix of u.*x and exclusive suffix of x over the K states of the sequence
-    __device__ __forceinline__ void scans(const real (&x)[SPL], real (&pre_ux)[SPL], real (&suf_x)[SPL]) const {
+    __device__ __forceinline__ void scans(const V (&x)[NP], V (&pre_ux)[NP], V (&suf_x)[NP]) const {
         real tu = real(0);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            pre_ux[i] = tu;
-            tu = fma_(u[i], x[i], tu);
+        for (int i = 0; i < 2 * NP; ++i) {
+            pre_ux[i >> 1][i & 1] = tu;
+            if (i < SPL) tu = fma_(get(u, i), get(x, i), tu);
         }
         real ta = real(0);
 #pragma unroll
-        for (int i = SPL - 1; i >= 0; --i) {
-            suf_x[i] = ta;
-            ta = ta + x[i];
+        for (int i = 2 * NP - 1; i >= 0; --i) {
+            suf_x[i >> 1][i & 1] = ta;
+            if (i < SPL) ta = ta + get(x, i);
         }
         if constexpr (R > 1) {
-            const real cu = g.excl_prefix(tu);
-            const real ca = g.excl_suffix(ta);
+            const V cu = splat<real>(g.excl_prefix(tu));
+            const V ca = splat<real>(g.excl_suffix(ta));
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) {
-                pre_ux[i] = pre_ux[i] + cu;
-                suf_x[i] = suf_x[i] + ca;
+            for (int h = 0; h < NP; ++h) {
+                pre_ux[h] = pre_ux[h] + cu;
+                suf_x[h] = suf_x[h] + ca;
             }
         }
     }
 
-    // One forward site (hmm.py:74-79): a <- ((a A) .* e_code) * 2^-ex with ex = exponent of the
-    // sum, so that sum(a) is in [0.5,1).  Returns ex; csum = the scaled sum.
+    // sum over the K states of the sequence (all lanes of the group get the same bits)
+    __device__ __forceinline__ real total(const V (&x)[NP]) const {
+        V acc = x[0];
+#pragma unroll
+        for (int h = 1; h < NP; ++h) acc = acc + x[h];
+        return g.sum(acc[0] + acc[1]);
+    }
+
+    // One forward site (hmm.py:74-79): a <- (a A) .* e_code, then, if SCALE, a *= 2^-ex with ex the
+    // exponent of the sum (so that sum(a) lands in [0.5,1)); returns ex (0 if !SCALE) and the scale.
     // code: 0 hom, 1 het, 2 missing (emission 1; hmm.py:70-71)
-    __device__ __forceinline__ int fwd_site(real (&a)[SPL], int code, real& csum) const {
-        real pre[SPL], suf[SPL], p[SPL];
+    __device__ __forceinline__ int fwd_site(V (&a)[NP], int code, real& scale, const bool SCALE) const {
+        V pre[NP], suf[NP], e[NP];
+        emis(code, e);
         scans(a, pre, suf);
-        const bool het = code == 1, miss = code == 2;
-        real c = real(0);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            real t = d[i] * a[i];
-            t = fma_(v[i], pre[i], t);
-            t = fma_(b[i], suf[i], t);
-            const real e = het ? e1[i] : e0[i];
-            const real te = t * e;
-            p[i] = miss ? t : te;
-            c = c + p[i];
+        for (int h = 0; h < NP; ++h) {
+            V t = d[h] * a[h];
+            t = fma2<real>(v[h], pre[h], t);
+            t = fma2<real>(b[h], suf[h], t);
+            a[h] = t * e[h];
         }
-        c = g.sum(c);
-        const int ex = frexp_exp_(c);
+        if (SCALE) {
+            const real c = total(a);
+            const int ex = frexp_exp_(c);
+            scale = ldexp_(real(1), -ex);  // exact power of two: the products below do not round
+            const V s2 = splat<real>(scale);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) a[i] = ldexp_(p[i], -ex);
-        csum = ldexp_(c, -ex);
-        return ex;
+            for (int h = 0; h < NP; ++h) a[h] = a[h] * s2;
+            return ex;
+        } else {
+            scale = real(1);
+            return 0;
+        }
     }
 
     // One backward site.  In: ap = alpha before the site, aq = alpha after it, beta = d ll/d aq,
-    // s = the 2^-ex applied at the site.  Out: beta = d ll / d ap; gradient rows accumulated:
+    // s = the scale applied at the site (SCALE) .  Out: beta = d ll / d ap; accumulated:
     //   gb += w.*suf(ap)   gd += w.*ap   gu += ap.*suf(v.*w)   gv += w.*pre(u.*ap)
     //   g0/g1 += aq.*beta  (divided by emis0/emis1 at the end)         with w = e.*beta*s
-    __device__ __forceinline__ void bwd_site(const real (&ap)[SPL], const real (&aq)[SPL], real (&beta)[SPL], int code,
-                                             real s, real (&gb)[SPL], real (&gd)[SPL], real (&gu)[SPL],
-                                             real (&gv)[SPL], real (&g0)[SPL], real (&g1)[SPL]) const {
-        const bool het = code == 1, miss = code == 2;
-        const real f1 = het ? real(1) : real(0);
-        const real f0 = code == 0 ? real(1) : real(0);
-        real pre[SPL], suf[SPL], w[SPL];
+    __device__ __forceinline__ void bwd_site(const V (&ap)[NP], const V (&aq)[NP], V (&beta)[NP], int code, real s,
+                                             const bool SCALE, V (&gb)[NP], V (&gd)[NP], V (&gu)[NP], V (&gv)[NP],
+                                             V (&g0)[NP], V (&g1)[NP]) const {
+        const V f1 = splat<real>(code == 1 ? real(1) : real(0));
+        const V f0 = splat<real>(code == 0 ? real(1) : real(0));
+        V pre[NP], suf[NP], w[NP], e[NP];
+        emis(code, e);
         scans(ap, pre, suf);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            const real m = aq[i] * beta[i];
-            g1[i] = fma_(f1, m, g1[i]);
-            g0[i] = fma_(f0, m, g0[i]);
-            const real bs = beta[i] * s;
-            const real e = het ? e1[i] : e0[i];
-            const real be = bs * e;
-            w[i] = miss ? bs : be;
+        for (int h = 0; h < NP; ++h) {
+            const V m = aq[h] * beta[h];
+            g1[h] = fma2<real>(f1, m, g1[h]);
+            g0[h] = fma2<real>(f0, m, g0[h]);
+            V t = beta[h] * e[h];
+            if (SCALE) t = t * splat<real>(s);
+            w[h] = t;
         }
         // suffix of v.*w and prefix of b.*w
-        real svw[SPL], pbw[SPL];
+        V svw[NP], pbw[NP];
         real tv = real(0);
 #pragma unroll
-        for (int i = SPL - 1; i >= 0; --i) {
-            svw[i] = tv;
-            tv = fma_(v[i], w[i], tv);
+        for (int i = 2 * NP - 1; i >= 0; --i) {
+            svw[i >> 1][i & 1] = tv;
+            if (i < SPL) tv = fma_(get(v, i), get(w, i), tv);
         }
         real tb = real(0);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            pbw[i] = tb;
-            tb = fma_(b[i], w[i], tb);
+        for (int i = 0; i < 2 * NP; ++i) {
+            pbw[i >> 1][i & 1] = tb;
+            if (i < SPL) tb = fma_(get(b, i), get(w, i), tb);
         }
         if constexpr (R > 1) {
-            const real cv = g.excl_suffix(tv);
-            const real cb = g.excl_prefix(tb);
+            const V cv = splat<real>(g.excl_suffix(tv));
+            const V cb = splat<real>(g.excl_prefix(tb));
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) {
-                svw[i] = svw[i] + cv;
-                pbw[i] = pbw[i] + cb;
+            for (int h = 0; h < NP; ++h) {
+                svw[h] = svw[h] + cv;
+                pbw[h] = pbw[h] + cb;
             }
         }
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-            gb[i] = fma_(w[i], suf[i], gb[i]);
-            gd[i] = fma_(w[i], ap[i], gd[i]);
-            gv[i] = fma_(w[i], pre[i], gv[i]);
-            gu[i] = fma_(ap[i], svw[i], gu[i]);
-            real nb = d[i] * w[i];
-            nb = nb + pbw[i];
-            beta[i] = fma_(u[i], svw[i], nb);
+        for (int h = 0; h < NP; ++h) {
+            gb[h] = fma2<real>(w[h], suf[h], gb[h]);
+            gd[h] = fma2<real>(w[h], ap[h], gd[h]);
+            gv[h] = fma2<real>(w[h], pre[h], gv[h]);
+            gu[h] = fma2<real>(ap[h], svw[h], gu[h]);
+            V nb = d[h] * w[h];
+            nb = nb + pbw[h];
+            beta[h] = fma2<real>(u[h], svw[h], nb);
         }
     }
 };
@@ -282,13 +336,26 @@ struct KArgs {
 
 constexpr double LN2 = 0.693147180559945309417232121458;
 
+// SCALE arguments of the site steps are compile-time constants after unrolling (the site loops
+// below are fully unrolled and the steps force-inlined), so the untaken side folds away.
+// Rescaling schedule: site t (0-based) is followed by a rescale iff t % NRM == NRM - 1.  T is a
+// multiple of NRM and blocks start at multiples of T, so the schedule is a function of the index
+// inside the block.  NRM = 1 is the reference's "normalise every site" (hmm.py:77-79).
+template <int NRM>
+__device__ __forceinline__ constexpr bool rescale_after(int i) { return (i % NRM) == NRM - 1; }
+
 // ---------------------------------------------------------------------------------------------
 // kernel 1: forward pass.  ll per sequence; optionally alpha checkpoints every T sites.
+// LDS: the per-thread emission table only.
 // ---------------------------------------------------------------------------------------------
-template <typename real, int K, int R, int T, bool CKPT>
+template <typename real, int K, int R, int T, int NRM, bool CKPT>
 __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
-    constexpr int SPL = K / R;
+    using L = Lane<real, K, R>;
+    using V = typename L::V;
+    constexpr int SPL = L::SPL, NP = L::NP;
     static_assert(T <= 16 && 16 % T == 0, "a block's codes must sit in one dword");
+    static_assert(T % NRM == 0, "the rescale schedule must restart with every block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int64_t nseq = A.B * A.S;
     const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
     const bool active = gid < nseq;
@@ -296,13 +363,13 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     const int rank = threadIdx.x & (R - 1);
     const int64_t bb = seq / A.S, ss = seq - bb * A.S;
 
-    Lane<real, K, R> lane;
-    real a[SPL];
-    lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank, a);
+    L lane;
+    V a[NP];
+    lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
+              (real*)smem_raw + (size_t)threadIdx.x * (3 * L::EROW), a);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
 
     int E = 0;
-    real csum = real(1);
     double llW = 0.0, invW = 0.0;
     const int64_t nblk = (A.Ltot + T - 1) / T;
     real* ck = (real*)A.ckpt;
@@ -312,69 +379,81 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
             if (active) {
                 real* dst = ck + (blk * nseq + seq) * K + rank * SPL;
 #pragma unroll
-                for (int i = 0; i < SPL; ++i) dst[i] = a[i];
+                for (int i = 0; i < SPL; ++i) dst[i] = L::get(a, i);
             }
         }
-        uint32_t codes = block_codes(words, t0);
+        const uint32_t codes = block_codes(words, t0);
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        for (int i = 0; i < ns; ++i) {
-            E += lane.fwd_site(a, codes & 3, csum);
-            codes >>= 2;
-            if (t0 + i + 1 == A.W) {
-                llW = log((double)csum) + (double)E * LN2;
-                invW = 1.0 / (double)csum;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (i < ns) {
+                real sc;
+                E += lane.fwd_site(a, (codes >> (2 * i)) & 3, sc, rescale_after<NRM>(i));
+                if (t0 + i + 1 == A.W) {
+                    asm volatile("; warm-up boundary" ::: "memory");  // keep this a real (uniform) branch
+                    const double cW = (double)lane.total(a);
+                    llW = log(cW) + (double)E * LN2;
+                    invW = 1.0 / cW;
+                }
             }
         }
     }
+    const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (active && rank == 0) {
-        // Ltot == 0: csum = 1, E = 0 -> ll = 0
-        A.ll[seq] = log((double)csum) + (double)E * LN2 - llW;
+        A.ll[seq] = log(cend) + (double)E * LN2 - llW;
         if constexpr (CKPT) {
-            A.aux[seq].inv_end = 1.0 / (double)csum;
+            A.aux[seq].inv_end = 1.0 / cend;
             A.aux[seq].inv_w = invW;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 2: backward sweep over the checkpointed blocks.
-// LDS: per site of the block, the SPL alpha values entering the site and the site's scale.
+// kernel 2: backward sweep over the checkpointed blocks.  The T alpha vectors of a block (and the
+// scales of its rescale sites) live in REGISTERS: both site loops are fully unrolled, so there is
+// no LDS block store and no address arithmetic; LDS holds only the emission table.
 // ---------------------------------------------------------------------------------------------
+// waves per SIMD the backward kernel is compiled for: 2 where T*SPL alphas + state fit 256 VGPRs
 template <typename real, int K, int R, int T>
-__global__ __launch_bounds__(NT_MAX) void bwd_kernel(KArgs A) {
-    constexpr int SPL = K / R;
+constexpr int bwd_waves_per_simd() { return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1; }
+
+template <typename real, int K, int R, int T, int NRM>
+__global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void bwd_kernel(KArgs A) {
+    using L = Lane<real, K, R>;
+    using V = typename L::V;
+    constexpr int SPL = L::SPL, NP = L::NP;
+    static_assert(T <= 16 && 16 % T == 0 && T % NRM == 0, "block / rescale schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    real* smem = (real*)smem_raw;  // [T][SPL+1][blockDim.x]
     const int tid = threadIdx.x;
     const int64_t nseq = A.B * A.S;
-    const int NT = blockDim.x;
-    const int64_t gid = (int64_t)blockIdx.x * (NT / R) + tid / R;
+    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + tid / R;
     const bool active = gid < nseq;
     const int64_t seq = active ? gid : nseq - 1;
     const int rank = tid & (R - 1);
     const int64_t bb = seq / A.S, ss = seq - bb * A.S;
 
-    Lane<real, K, R> lane;
-    real pi[SPL];
+    L lane;
+    V pi[NP];
     const real* prm = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
-    lane.load(prm, rank, pi);
+    real* etab = (real*)smem_raw + (size_t)tid * (3 * L::EROW);
+    lane.load(prm, rank, etab, pi);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
     const real* ck = (const real*)A.ckpt;
 
-    real beta[SPL], gb[SPL], gd[SPL], gu[SPL], gv[SPL], g0[SPL], g1[SPL];
+    V beta[NP], gb[NP], gd[NP], gu[NP], gv[NP], g0[NP], g1[NP];
     const real inv_end = (real)A.aux[seq].inv_end;
     const real inv_w = (real)A.aux[seq].inv_w;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-        beta[i] = inv_end;
-        gb[i] = gd[i] = gu[i] = gv[i] = g0[i] = g1[i] = real(0);
+    for (int h = 0; h < NP; ++h) {
+        beta[h] = splat<real>(inv_end);
+        gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
     }
     constexpr bool F64ACC = sizeof(real) == 4;  // f32 kernels fold partial sums into f64
     double* gacc = A.gacc + seq * 6 * K + rank * SPL;
     int since_flush = 0;
 
     const int64_t nblk = (A.Ltot + T - 1) / T;
-    real a[SPL], anext[SPL];
+    real anext[SPL];
     if (nblk > 0) {
         const real* src = ck + ((nblk - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
@@ -382,8 +461,13 @@ __global__ __launch_bounds__(NT_MAX) void bwd_kernel(KArgs A) {
     }
     for (int64_t blk = nblk - 1; blk >= 0; --blk) {
         const int64_t t0 = blk * T;
+        V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
+        real sc[T / NRM];
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) a[i] = anext[i];
+        for (int h = 0; h < NP; ++h) {
+            al[0][h][0] = anext[2 * h];
+            al[0][h][1] = (2 * h + 1 < SPL) ? anext[(2 * h + 1 < SPL) ? 2 * h + 1 : 0] : real(0);
+        }
         if (blk > 0) {  // prefetch the previous block's checkpoint under this block's arithmetic
             const real* src = ck + ((blk - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
@@ -391,29 +475,30 @@ __global__ __launch_bounds__(NT_MAX) void bwd_kernel(KArgs A) {
         }
         const uint32_t codes = block_codes(words, t0);
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        // re-run the block forward, keeping alpha_{t-1} and the scale of every site
-        for (int i = 0; i < ns; ++i) {
-            real* row = smem + (size_t)i * (SPL + 1) * NT + tid;
+        // re-run the block forward (bit-identical to kernel 1), keeping every alpha
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) row[j * NT] = a[j];
-            real csum;
-            const int ex = lane.fwd_site(a, (codes >> (2 * i)) & 3, csum);
-            row[SPL * NT] = ldexp_(real(1), -ex);
-        }
-        // sweep it backwards; a = alpha after site i
-        for (int i = ns - 1; i >= 0; --i) {
-            if (t0 + i + 1 == A.W) {
+        for (int i = 0; i < T; ++i) {
+            if (i < ns) {
 #pragma unroll
-                for (int j = 0; j < SPL; ++j) beta[j] = beta[j] - inv_w;
+                for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
+                real s;
+                lane.fwd_site(al[i + 1], (codes >> (2 * i)) & 3, s, rescale_after<NRM>(i));
+                if (rescale_after<NRM>(i)) sc[i / NRM] = s;
             }
-            const real* row = smem + (size_t)i * (SPL + 1) * NT + tid;
-            real ap[SPL];
+        }
+        // sweep it backwards
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) ap[j] = row[j * NT];
-            const real s = row[SPL * NT];
-            lane.bwd_site(ap, a, beta, (codes >> (2 * i)) & 3, s, gb, gd, gu, gv, g0, g1);
+        for (int i = T - 1; i >= 0; --i) {
+            if (i < ns) {
+                if (t0 + i + 1 == A.W) {
+                    asm volatile("; warm-up boundary" ::: "memory");  // keep this a real (uniform) branch
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) a[j] = ap[j];
+                    for (int h = 0; h < NP; ++h) beta[h] = beta[h] - splat<real>(inv_w);
+                }
+                const bool SC = rescale_after<NRM>(i);
+                lane.bwd_site(al[i], al[i + 1], beta, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC, gb, gd,
+                              gu, gv, g0, g1);
+            }
         }
         if constexpr (F64ACC) {
             since_flush += ns;
@@ -422,16 +507,16 @@ __global__ __launch_bounds__(NT_MAX) void bwd_kernel(KArgs A) {
                 if (active) {
 #pragma unroll
                     for (int i = 0; i < SPL; ++i) {
-                        gacc[0 * K + i] += (double)gb[i];
-                        gacc[1 * K + i] += (double)gd[i];
-                        gacc[2 * K + i] += (double)gu[i];
-                        gacc[3 * K + i] += (double)gv[i];
-                        gacc[4 * K + i] += (double)g0[i];
-                        gacc[5 * K + i] += (double)g1[i];
+                        gacc[0 * K + i] += (double)L::get(gb, i);
+                        gacc[1 * K + i] += (double)L::get(gd, i);
+                        gacc[2 * K + i] += (double)L::get(gu, i);
+                        gacc[3 * K + i] += (double)L::get(gv, i);
+                        gacc[4 * K + i] += (double)L::get(g0, i);
+                        gacc[5 * K + i] += (double)L::get(g1, i);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < SPL; ++i) gb[i] = gd[i] = gu[i] = gv[i] = g0[i] = g1[i] = real(0);
+                for (int h = 0; h < NP; ++h) gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
             }
         }
     }
@@ -446,15 +531,16 @@ __global__ __launch_bounds__(NT_MAX) void bwd_kernel(KArgs A) {
             vb = gacc[0 * K + i]; vd = gacc[1 * K + i]; vu = gacc[2 * K + i];
             vv = gacc[3 * K + i]; v0 = gacc[4 * K + i]; v1 = gacc[5 * K + i];
         } else {
-            vb = gb[i]; vd = gd[i]; vu = gu[i]; vv = gv[i]; v0 = g0[i]; v1 = g1[i];
+            vb = L::get(gb, i); vd = L::get(gd, i); vu = L::get(gu, i);
+            vv = L::get(gv, i); v0 = L::get(g0, i); v1 = L::get(g1, i);
         }
-        out[0 * K + i] = (real)(dl ? vb * (double)lane.b[i] : vb);
-        out[1 * K + i] = (real)(dl ? vd * (double)lane.d[i] : vd);
-        out[2 * K + i] = (real)(dl ? vu * (double)lane.u[i] : vu);
-        out[3 * K + i] = (real)(dl ? vv * (double)lane.v[i] : vv);
-        out[4 * K + i] = (real)(dl ? v0 : v0 / (double)lane.e0[i]);
-        out[5 * K + i] = (real)(dl ? v1 : v1 / (double)lane.e1[i]);
-        out[6 * K + i] = (real)(dl ? (double)beta[i] * (double)pi[i] : (double)beta[i]);
+        out[0 * K + i] = (real)(dl ? vb * (double)L::get(lane.b, i) : vb);
+        out[1 * K + i] = (real)(dl ? vd * (double)L::get(lane.d, i) : vd);
+        out[2 * K + i] = (real)(dl ? vu * (double)L::get(lane.u, i) : vu);
+        out[3 * K + i] = (real)(dl ? vv * (double)L::get(lane.v, i) : vv);
+        out[4 * K + i] = (real)(dl ? v0 : v0 / (double)etab[0 * L::EROW + i]);
+        out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + i]);
+        out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)L::get(pi, i) : (double)L::get(beta, i));
     }
 }
 

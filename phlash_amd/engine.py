@@ -58,6 +58,9 @@ class HipEngine:
     def set_variant(self, R: int = 0, T: int = 0):
         _lib.check(_lib.load().phk_set_variant(self._h, int(R), int(T)))
 
+    def set_rescale_interval(self, nrm: int = 0):
+        _lib.check(_lib.load().phk_set_rescale_interval(self._h, int(nrm)))
+
     def get_variant(self, B: int, S: int) -> tuple[int, int]:
         r, t = ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.load().phk_get_variant(self._h, int(B), int(S), ctypes.byref(r), ctypes.byref(t)))

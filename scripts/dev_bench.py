@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--L", type=int, default=60000)
     ap.add_argument("--W", type=int, default=500)
     ap.add_argument("--dbl", type=int, default=0)
-    ap.add_argument("--variants", default="1:8,2:8,4:8,8:8,16:8,1:16,2:16,4:16,8:16,16:16")
+    ap.add_argument("--variants", default="1:8:2,2:8:1,2:8:2,2:8:4,4:8:2,4:8:4,4:16:4,8:8:2,16:8:2", help="R:T:NRM,...")
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     rng = np.random.default_rng(0)
@@ -43,9 +43,10 @@ def main():
     work = a.B * a.S * a.L
     print(f"K={K} B={a.B} S={a.S} L={a.L} W={a.W} dbl={a.dbl} work={work:.3e} site-particles")
     for v in a.variants.split(","):
-        R, T = (int(x) for x in v.split(":"))
+        R, T, NRM = (int(x) for x in v.split(":"))
         try:
             eng.set_variant(R, T)
+            eng.set_rescale_interval(NRM)
         except AssertionError as e:
             print(f"R={R:2d} T={T:2d} skipped: {e}")
             continue
@@ -60,7 +61,7 @@ def main():
             if best is None or f + b < best[0] + best[1]:
                 best = (f, b, wall * 1e3, n)
         f, b, wall, n = best
-        print(f"R={R:2d} T={T:2d} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall:8.2f} ms launches={n} "
+        print(f"R={R:2d} T={T:2d} NRM={NRM} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall:8.2f} ms launches={n} "
               f"-> {work / ((f + b) * 1e-3):.3e} site-particle/s  ws={eng.workspace_bytes() / 2**30:.1f} GiB "
               f"ll0={float(ll[0, 0]):.4f} finite={bool(torch.isfinite(g).all())}", flush=True)
 

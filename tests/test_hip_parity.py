@@ -62,21 +62,18 @@ def _check(ll, g, ll_ref, g_ref, dbl):
         assert err.max() < gtol, f"gradient error {err.max():.3e} (row-scaled) >= {gtol}"
 
 
-VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (2, 16), (4, 16), (16, 16)]
+VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (4, 16), (8, 16), (16, 16)]
 
 
 @pytest.mark.parametrize("dbl", [True, False])
+@pytest.mark.parametrize("nrm", [1, 2, 4])
 @pytest.mark.parametrize("R,T", VARIANTS_16)
 @pytest.mark.parametrize("W", [0, 100])
-def test_k16_all_variants(missing_data, R, T, W, dbl):
-    if dbl and (R, T) == (1, 16):
-        pytest.skip("f64 R=1 T=16 does not fit the LDS")
+def test_k16_all_variants(missing_data, R, T, W, nrm, dbl):
     data = missing_data
     eng = _engine(16, data, dbl)
-    try:
-        eng.set_variant(R, T)
-    except AssertionError:
-        pytest.skip("variant does not fit")
+    eng.set_variant(R, T)
+    eng.set_rescale_interval(nrm)
     B, S = 3, len(data)
     P = _params(16, B, 1, seed=7)
     inds = np.arange(S)
@@ -94,16 +91,15 @@ def test_other_K(K, R, dbl, rng):
     data = (rng.uniform(size=(6, 700)) < 0.08).astype(np.int8)
     data.flat[rng.integers(0, data.size, 40)] = -1
     eng = _engine(K, data, dbl)
-    try:
-        eng.set_variant(R, 8)
-    except AssertionError:
-        pytest.skip("variant does not fit")
+    eng.set_variant(R, 8)
     P = _params(K, 2, 1, seed=3)
     inds = np.array([5, 0, 3, 3])
-    for W in (0, 64):
-        ll, g = _run(eng, P, inds, W)
-        ll_ref, g_ref = cport.batch(P, data, inds, W)
-        _check(ll, g, ll_ref, g_ref, dbl)
+    for nrm in (1, 2, 4):
+        eng.set_rescale_interval(nrm)
+        for W in (0, 64):
+            ll, g = _run(eng, P, inds, W)
+            ll_ref, g_ref = cport.batch(P, data, inds, W)
+            _check(ll, g, ll_ref, g_ref, dbl)
 
 
 @pytest.mark.parametrize("L", [1, 2, 7, 8, 9, 15, 16, 17, 33, 1003])
@@ -113,8 +109,9 @@ def test_ragged_lengths(L, rng):
     eng = _engine(16, data, True)
     P = _params(16, 2, 1, seed=1)
     inds = np.arange(3)
-    for R, T in [(1, 8), (4, 8), (16, 16)]:
+    for R, T, nrm in [(1, 8, 1), (4, 8, 4), (16, 16, 2), (2, 8, 4)]:
         eng.set_variant(R, T)
+        eng.set_rescale_interval(nrm)
         for W in sorted({0, min(3, L), L}):
             ll, g = _run(eng, P, inds, W)
             ll_ref, g_ref = cport.batch(P, data, inds, W)
@@ -190,5 +187,9 @@ def test_errors(data):
     eng = HipEngine(16, data)
     with pytest.raises(AssertionError):
         eng.set_variant(3, 8)
+    with pytest.raises(AssertionError):
+        eng.set_variant(2, 16)  # T = 16 only where a lane owns <= 4 states
+    with pytest.raises(AssertionError):
+        eng.set_rescale_interval(3)
     with pytest.raises(AssertionError):
         _run(eng, _params(16, 1, 1, 0), np.arange(2), 5000)
