@@ -224,9 +224,8 @@ struct Lane {
     // One forward site (hmm.py:74-79): a <- (a A) .* e_code, then, if SCALE, a *= 2^-ex with ex the
     // exponent of the sum (so that sum(a) lands in [0.5,1)); returns ex (0 if !SCALE) and the scale.
     // code: 0 hom, 1 het, 2 missing (emission 1; hmm.py:70-71)
-    __device__ __forceinline__ int fwd_site(V (&a)[NP], int code, real& scale, const bool SCALE) const {
-        V pre[NP], suf[NP], e[NP];
-        emis(code, e);
+    __device__ __forceinline__ int fwd_site(V (&a)[NP], const V (&e)[NP], real& scale, const bool SCALE) const {
+        V pre[NP], suf[NP];
         scans(a, pre, suf);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
@@ -253,13 +252,12 @@ struct Lane {
     // s = the scale applied at the site (SCALE) .  Out: beta = d ll / d ap; accumulated:
     //   gb += w.*suf(ap)   gd += w.*ap   gu += ap.*suf(v.*w)   gv += w.*pre(u.*ap)
     //   g0/g1 += aq.*beta  (divided by emis0/emis1 at the end)         with w = e.*beta*s
-    __device__ __forceinline__ void bwd_site(const V (&ap)[NP], const V (&aq)[NP], V (&beta)[NP], int code, real s,
-                                             const bool SCALE, V (&gb)[NP], V (&gd)[NP], V (&gu)[NP], V (&gv)[NP],
-                                             V (&g0)[NP], V (&g1)[NP]) const {
+    __device__ __forceinline__ void bwd_site(const V (&ap)[NP], const V (&aq)[NP], V (&beta)[NP], const V (&e)[NP],
+                                             int code, real s, const bool SCALE, V (&gb)[NP], V (&gd)[NP], V (&gu)[NP],
+                                             V (&gv)[NP], V (&g0)[NP], V (&g1)[NP]) const {
         const V f1 = splat<real>(code == 1 ? real(1) : real(0));
         const V f0 = splat<real>(code == 0 ? real(1) : real(0));
-        V pre[NP], suf[NP], w[NP], e[NP];
-        emis(code, e);
+        V pre[NP], suf[NP], w[NP];
         scans(ap, pre, suf);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
@@ -344,6 +342,14 @@ constexpr double LN2 = 0.693147180559945309417232121458;
 template <int NRM>
 __device__ __forceinline__ constexpr bool rescale_after(int i) { return (i % NRM) == NRM - 1; }
 
+// The backward kernel has a straight-line path for full blocks (no per-site branches, next
+// emission row prefetched).  It needs a few more live registers than the guarded loop; where the
+// T alpha vectors already fill the 256-VGPR budget of 2 waves/SIMD (f32: more than 4 states per
+// lane) it spills and runs 4x slower (measured, R=2: 153 ms vs 40 ms), so it is compiled only
+// where it fits (measured, R=4: 47 ms vs 56 ms).
+template <typename real, int K, int R, int T>
+constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 128; }
+
 // ---------------------------------------------------------------------------------------------
 // kernel 1: forward pass.  ll per sequence; optionally alpha checkpoints every T sites.
 // LDS: the per-thread emission table only.
@@ -384,16 +390,36 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         }
         const uint32_t codes = block_codes(words, t0);
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
+        if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+            // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
+            // the scheduler can lift every emission ds_read to the top and overlap sites
+            V ec[NP];
+            lane.emis(codes & 3, ec);
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if (i < ns) {
+            for (int i = 0; i < T; ++i) {
+                V en[NP];  // next site's emission row is in flight while this site computes
+                if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
                 real sc;
-                E += lane.fwd_site(a, (codes >> (2 * i)) & 3, sc, rescale_after<NRM>(i));
-                if (t0 + i + 1 == A.W) {
-                    asm volatile("; warm-up boundary" ::: "memory");  // keep this a real (uniform) branch
-                    const double cW = (double)lane.total(a);
-                    llW = log(cW) + (double)E * LN2;
-                    invW = 1.0 / cW;
+                E += lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
+                if (i + 1 < T) {
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (i < ns) {
+                    real sc;
+                    V e[NP];
+                    lane.emis((codes >> (2 * i)) & 3, e);
+                    E += lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
+                    if (t0 + i + 1 == A.W) {
+                        const double cW = (double)lane.total(a);
+                        llW = log(cW) + (double)E * LN2;
+                        invW = 1.0 / cW;
+                    }
                 }
             }
         }
@@ -475,29 +501,69 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         }
         const uint32_t codes = block_codes(words, t0);
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        // re-run the block forward (bit-identical to kernel 1), keeping every alpha
+        if (bwd_straight_line<real, K, R, T>() && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+            // full block, no warm-up boundary inside: straight-line code for all 2T site steps.
+            // re-run the block forward (bit-identical to kernel 1), keeping every alpha; the
+            // emission row of the NEXT step is always in flight while the current one computes,
+            // and a scheduling barrier after every step keeps the live ranges of its temporaries
+            // from being stretched over its neighbours (the kernel sits at the 256-VGPR budget).
+            V ec[NP];
+            lane.emis(codes & 3, ec);
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if (i < ns) {
+            for (int i = 0; i < T; ++i) {
+                V en[NP];
+                if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
 #pragma unroll
                 for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
                 real s;
-                lane.fwd_site(al[i + 1], (codes >> (2 * i)) & 3, s, rescale_after<NRM>(i));
+                lane.fwd_site(al[i + 1], ec, s, rescale_after<NRM>(i));
                 if (rescale_after<NRM>(i)) sc[i / NRM] = s;
-            }
-        }
-        // sweep it backwards
+                if (i + 1 < T) {  // (the last forward step and the first backward step share a row)
 #pragma unroll
-        for (int i = T - 1; i >= 0; --i) {
-            if (i < ns) {
-                if (t0 + i + 1 == A.W) {
-                    asm volatile("; warm-up boundary" ::: "memory");  // keep this a real (uniform) branch
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) beta[h] = beta[h] - splat<real>(inv_w);
+                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // sweep it backwards
+#pragma unroll
+            for (int i = T - 1; i >= 0; --i) {
+                V en[NP];
+                if (i > 0) lane.emis((codes >> (2 * (i - 1))) & 3, en);
                 const bool SC = rescale_after<NRM>(i);
-                lane.bwd_site(al[i], al[i + 1], beta, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC, gb, gd,
-                              gu, gv, g0, g1);
+                lane.bwd_site(al[i], al[i + 1], beta, ec, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC, gb,
+                              gd, gu, gv, g0, g1);
+                if (i > 0) {
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (i < ns) {
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
+                    real s;
+                    V e[NP];
+                    lane.emis((codes >> (2 * i)) & 3, e);
+                    lane.fwd_site(al[i + 1], e, s, rescale_after<NRM>(i));
+                    if (rescale_after<NRM>(i)) sc[i / NRM] = s;
+                }
+            }
+#pragma unroll
+            for (int i = T - 1; i >= 0; --i) {
+                if (i < ns) {
+                    if (t0 + i + 1 == A.W) {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) beta[h] = beta[h] - splat<real>(inv_w);
+                    }
+                    const bool SC = rescale_after<NRM>(i);
+                    V e[NP];
+                    lane.emis((codes >> (2 * i)) & 3, e);
+                    lane.bwd_site(al[i], al[i + 1], beta, e, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC,
+                                  gb, gd, gu, gv, g0, g1);
+                }
             }
         }
         if constexpr (F64ACC) {
