@@ -133,17 +133,14 @@ def main():
     for _ in range(a.warmup):
         state = one_step(state)
     barrier()
-    fwd_ms = bwd_ms = 0.0
+    kern._eng.timing_totals()  # drop the warm-up steps' events
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        state = one_step(state)
-        # event times of this step's kernels (HIP events on the launch stream; waiting on them
-        # here is a host-side wait for work the next step depends on anyway)
-        f, b, _n = kern._eng.last_timing()
-        fwd_ms += f
-        bwd_ms += b
+        state = one_step(state)  # no host synchronisation inside the timed loop
     barrier()
     elapsed = time.perf_counter() - t0
+    # HIP events recorded around the kernels on their launch stream, resolved once, after the loop
+    fwd_ms, bwd_ms, _n = kern._eng.timing_totals()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -95,6 +95,9 @@ int64_t phk_workspace_bytes(phk_handle* h);
  * kernels of the last call (ms) and the number of launches of each. */
 int phk_set_profiling(phk_handle* h, int on);
 int phk_last_timing(phk_handle* h, float* fwd_ms, float* bwd_ms, int* n_launches);
+/* Same, summed over every call since the previous phk_timing_totals (or since profiling was
+ * switched on); waits once, at query time, so a timed loop needs no per-step synchronisation. */
+int phk_timing_totals(phk_handle* h, double* fwd_ms, double* bwd_ms, int* n_launches);
 
 #ifdef __cplusplus
 }

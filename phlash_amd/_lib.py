@@ -32,6 +32,7 @@ SIGNATURES = {
     "phk_workspace_bytes": (_i64, [_vp]),
     "phk_set_profiling": (_i, [_vp, _i]),
     "phk_last_timing": (_i, [_vp, _fp, _fp, _ip]),
+    "phk_timing_totals": (_i, [_vp, _dp, _dp, _ip]),
 }
 
 

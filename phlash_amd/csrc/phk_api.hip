@@ -82,8 +82,9 @@ struct phk_handle {
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int profiling = 0;
-    std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch pair of the last call
-    int n_launches = 0;
+    std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch pair since the last timing query
+    int n_launches = 0;          // launch pairs recorded since the last query
+    int n_last = 0;              // ... of which by the last call
 };
 
 namespace {
@@ -263,6 +264,24 @@ int phk_set_profiling(phk_handle* h, int on) {
 int phk_last_timing(phk_handle* h, float* fwd_ms, float* bwd_ms, int* n_launches) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     float f = 0.f, b = 0.f;
+    for (int i = h->n_launches - h->n_last; i < h->n_launches; ++i) {
+        hipEvent_t e0 = h->ev[3 * i], e1 = h->ev[3 * i + 1], e2 = h->ev[3 * i + 2];
+        HIP_TRY(hipEventSynchronize(e2));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        f += t;
+        HIP_TRY(hipEventElapsedTime(&t, e1, e2));
+        b += t;
+    }
+    if (fwd_ms) *fwd_ms = f;
+    if (bwd_ms) *bwd_ms = b;
+    if (n_launches) *n_launches = h->n_last;
+    return PHK_OK;
+}
+
+int phk_timing_totals(phk_handle* h, double* fwd_ms, double* bwd_ms, int* n_launches) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    double f = 0.0, b = 0.0;
     for (int i = 0; i < h->n_launches; ++i) {
         hipEvent_t e0 = h->ev[3 * i], e1 = h->ev[3 * i + 1], e2 = h->ev[3 * i + 2];
         HIP_TRY(hipEventSynchronize(e2));
@@ -275,6 +294,8 @@ int phk_last_timing(phk_handle* h, float* fwd_ms, float* bwd_ms, int* n_launches
     if (fwd_ms) *fwd_ms = f;
     if (bwd_ms) *bwd_ms = b;
     if (n_launches) *n_launches = h->n_launches;
+    h->n_launches = 0;  // events are recycled from here on
+    h->n_last = 0;
     return PHK_OK;
 }
 
@@ -293,7 +314,8 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     const size_t rs = real_size(h);
     const int K = h->K;
     const bool want_grad = grad != nullptr;
-    h->n_launches = 0;
+    h->n_last = 0;
+    if (h->n_launches > 4096) h->n_launches = 0;  // nobody is collecting: recycle the event pool
 
     int R = 1, T = 8;
     choose_variant(h, B * S, &R, &T);
@@ -369,6 +391,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
             if (h->profiling) {
                 HIP_TRY(hipEventRecord(e2, st));
                 h->n_launches++;
+                h->n_last++;
             }
         }
     }

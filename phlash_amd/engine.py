@@ -80,6 +80,12 @@ class HipEngine:
         _lib.check(_lib.load().phk_last_timing(self._h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
         return f.value, b.value, n.value
 
+    def timing_totals(self) -> tuple[float, float, int]:
+        """(forward ms, backward ms, launches) summed over all calls since the last query."""
+        f, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(_lib.load().phk_timing_totals(self._h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
+        return f.value, b.value, n.value
+
     # ---- the operator -----------------------------------------------------------------------
     def run(self, params: torch.Tensor, inds: torch.Tensor, warmup: int = 0, grad: bool = True, dlog: bool = False):
         """params [B, S, 7, K] or [B, 1, 7, K] (one block per particle, broadcast over the chunks);

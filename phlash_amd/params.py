@@ -21,7 +21,7 @@ import torch
 
 from .size_history import DemographicModel, SizeHistory, _f64
 from .transition import transition_factors
-from .util import Pattern, softplus_inv
+from .util import Pattern, get_pattern, softplus_inv
 
 F64 = torch.float64
 ROWS = ("b", "d", "u", "v", "emis0", "emis1", "pi")
@@ -113,7 +113,7 @@ class MCMCParams:
         return torch.cat([self.t_tr, self.c_tr, self.rho_over_theta_tr[..., None]], -1)
 
     def from_flat(self, x: torch.Tensor) -> "MCMCParams":
-        P = len(Pattern(self.pattern))
+        P = len(get_pattern(self.pattern))
         assert x.shape[-1] == P + 3
         return dataclasses.replace(self, t_tr=x[..., :2], c_tr=x[..., 2 : 2 + P], rho_over_theta_tr=x[..., 2 + P])
 
@@ -147,7 +147,7 @@ class MCMCParams:
 
     def to_dm(self) -> DemographicModel:
         """params.py:94-104: t = [0, geomspace(t1, tM, M-1)], c expanded by the pattern."""
-        pat = Pattern(self.pattern)
+        pat = get_pattern(self.pattern)
         assert pat.M >= 3
         assert self.c.shape[-1] == len(pat)
         t1, tM = self.t

@@ -22,9 +22,13 @@ F64 = torch.float64
 
 
 def _f64(x, like=None):
+    """float64 tensor on ``like``'s device.  Python scalars become 0-dim tensors by a device-side
+    fill (no host-to-device copy, so no stream synchronisation inside the SVGD step)."""
     if isinstance(x, torch.Tensor):
         return x.to(F64)
     dev = like.device if isinstance(like, torch.Tensor) else None
+    if isinstance(x, (int, float)):
+        return torch.full((), float(x), dtype=F64, device=dev)
     return torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=F64, device=dev)
 
 

@@ -26,7 +26,7 @@ import torch
 @dataclasses.dataclass
 class SVGDState:
     particles: torch.Tensor  # [n, D]
-    length_scale: float
+    length_scale: torch.Tensor  # 0-dim tensor on the particles' device (no host sync per step)
     mu: torch.Tensor
     nu: torch.Tensor
     nu_max: torch.Tensor
@@ -35,10 +35,11 @@ class SVGDState:
 
 def init(particles: torch.Tensor) -> SVGDState:
     z = torch.zeros_like(particles)
-    return SVGDState(particles=particles, length_scale=1.0, mu=z, nu=z.clone(), nu_max=z.clone(), count=0)
+    one = torch.ones((), dtype=particles.dtype, device=particles.device)
+    return SVGDState(particles=particles, length_scale=one, mu=z, nu=z.clone(), nu_max=z.clone(), count=0)
 
 
-def functional_gradient(x: torch.Tensor, grad_logp: torch.Tensor, h: float) -> torch.Tensor:
+def functional_gradient(x: torch.Tensor, grad_logp: torch.Tensor, h) -> torch.Tensor:
     """phi [n, D] as defined in the module docstring."""
     n = x.shape[0]
     diff = x[:, None, :] - x[None, :, :]  # [i, j] = x_i - x_j
@@ -47,14 +48,15 @@ def functional_gradient(x: torch.Tensor, grad_logp: torch.Tensor, h: float) -> t
     return (-(k.T @ grad_logp) - grad_k_i.sum(0)) / n
 
 
-def median_heuristic(x: torch.Tensor) -> float:
+def median_heuristic(x: torch.Tensor) -> torch.Tensor:
+    """median(pairwise distances)^2 / log(n), as a 0-dim tensor (stays on the device)."""
     n = x.shape[0]
     if n < 2:
-        return 1.0
+        return torch.ones((), dtype=x.dtype, device=x.device)
     d = torch.cdist(x, x)
     iu = torch.tril_indices(n, n, offset=-1, device=x.device)
     med = torch.quantile(d[iu[0], iu[1]], 0.5)
-    return float(med**2 / math.log(n))
+    return med**2 / math.log(n)
 
 
 def amsgrad_update(state: SVGDState, g: torch.Tensor, lr: float, b1=0.9, b2=0.999, eps=1e-8):

@@ -3,6 +3,7 @@ Behaviour follows the reference's ``Pattern`` / ``softplus_inv`` (src/phlash/uti
 
 from __future__ import annotations
 
+import functools
 import re
 
 import torch
@@ -29,6 +30,7 @@ class Pattern:
             raise ValueError("epochs must be positive")
         self.pattern = pattern
         self._widths = tuple(widths)
+        self._index_cache: dict = {}
 
     @property
     def widths(self) -> tuple[int, ...]:
@@ -49,13 +51,25 @@ class Pattern:
         if isinstance(x, torch.Tensor):
             if x.shape[-1] != len(self):
                 raise AssertionError("one value per epoch expected")
-            return torch.repeat_interleave(x, torch.tensor(self._widths, device=x.device), dim=-1)
+            # gather with a cached per-device index (repeat_interleave with tensor repeats would
+            # synchronise the stream to learn its output size)
+            idx = self._index_cache.get(x.device)
+            if idx is None:
+                host = [e for e, w in enumerate(self._widths) for _ in range(w)]
+                idx = self._index_cache[x.device] = torch.tensor(host, dtype=torch.int64, device=x.device)
+            return x.index_select(-1, idx)
         if len(x) != len(self):
             raise AssertionError("one value per epoch expected")
         out = []
         for w, v in zip(self._widths, x):
             out.extend([v] * w)
         return out
+
+
+@functools.lru_cache(maxsize=64)
+def get_pattern(pattern: str) -> Pattern:
+    """Shared, cached Pattern (keeps its per-device expansion index across calls)."""
+    return Pattern(pattern)
 
 
 def softplus_inv(y):

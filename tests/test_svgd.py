@@ -43,7 +43,7 @@ def test_amsgrad_first_steps():
     upd, mu, nu, nu_max, count = svgd.amsgrad_update(st, g, lr=0.1)
     # first step of a bias-corrected Adam-family update is -lr * sign(g) (up to eps)
     np.testing.assert_allclose(upd, [[-0.1, 0.1]], rtol=1e-6)
-    st = svgd.SVGDState(st.particles, 1.0, mu, nu, nu_max, count)
+    st = svgd.SVGDState(st.particles, st.length_scale, mu, nu, nu_max, count)
     upd2, *_ = svgd.amsgrad_update(st, 0.1 * g, lr=0.1)
     # second moment max is kept: the step cannot grow when the gradient shrinks
     assert float(upd2.abs().max()) < 0.1
