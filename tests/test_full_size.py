@@ -1,0 +1,137 @@
+"""GPU tests at BASELINE.json's full sizes (cfg1, cfg2, cfg4, cfg5 shapes).  The float64 oracle is
+too slow to check every sequence at these sizes, so it checks a bounded sample and the rest is
+covered by size-independent properties of the domain:
+
+* the gradient kernel and the no-gradient kernel return the same log-likelihood (tests/test_gpu.py:34-40);
+* sum_i pi_i * d ll / d pi_i = 1 (no warm-up) -- the backward sweep ends on a normalised posterior;
+* sum_j gamma_0[j] + gamma_1[j] = number of non-missing sites (posterior state marginals sum to 1 per site);
+* log-likelihood additivity over a split: ll(row, W=0) = ll(row[:W], W=0) + ll(row, W);
+* results do not depend on the kernel variant (lanes per sequence, rescale interval) nor on the
+  workspace slabbing;
+* a directional finite difference of ll along a random parameter direction matches <grad, dir>.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _setup(K, B, S, L, W, dbl, seed=0):
+    from phlash_amd.engine import HipEngine
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import particle_population, simulate_chunks
+
+    data = simulate_chunks(K, S, W + L, seed=seed)
+    tmpl, x = particle_population(K, B, seed=1, sigma=0.25)
+    P = PSMCParams.from_dm(tmpl.from_flat(x).to_dm()).stack()[:, None].cuda()
+    eng = HipEngine(K, data, double_precision=dbl)
+    return data, P, eng
+
+
+def test_cfg1_single_long_chunk():
+    """cfg1: one 10 Mb chunk (100,000 sites), K = 16, 1 particle; f32 and f64 against the oracle."""
+    data, P, e64 = _setup(16, 1, 1, 100_000, 0, True)
+    from phlash_amd.engine import HipEngine
+
+    e32 = HipEngine(16, data, double_precision=False)
+    inds = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ll_ref, g_ref = cport.batch(P.cpu().numpy(), data, [0], 0)
+    for eng, tol, gtol in ((e64, 1e-11, 1e-8), (e32, 1e-5, 2e-3)):
+        for R in (1, 4, 16):
+            eng.set_variant(R, 8)
+            ll, g = eng.run(P, inds, 0, grad=True)
+            np.testing.assert_allclose(ll.cpu().numpy(), ll_ref, rtol=tol)
+            scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1e-300)
+            assert (np.abs(g.double().cpu().numpy() - g_ref) / scale).max() < gtol
+
+
+@pytest.mark.parametrize("dbl", [False, True])
+def test_cfg2_properties(dbl):
+    """cfg2 shape: 500 chunks x 60,000 scored sites (+500 warm-up), K = 16; 12 particles keep the
+    test short (the per-sequence work is what cfg2 has)."""
+    K, B, S, L, W = 16, 12, 500, 60_000, 500
+    data, P, eng = _setup(K, B, S, L, W, dbl)
+    inds = torch.arange(S, device="cuda")
+    ll, g = eng.run(P, inds, W, grad=True)
+    ll0 = eng.run(P, inds, W, grad=False)
+    assert torch.isfinite(ll).all() and torch.isfinite(g).all()
+    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-12 if dbl else 1e-7)
+    # bounded oracle sample: 3 particles x 6 chunks at full length
+    sub = [0, 7, 11]
+    chunks = [0, 123, 250, 333, 498, 499]
+    ll_ref, g_ref = cport.batch(P[sub].cpu().numpy(), data, chunks, W)
+    got = ll[sub][:, chunks].cpu().numpy()
+    np.testing.assert_allclose(got, ll_ref, rtol=1e-10 if dbl else 1e-5)
+    gg = g[sub][:, chunks].double().cpu().numpy()
+    scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+    assert (np.abs(gg - g_ref) / scale).max() < (1e-7 if dbl else 2e-3)
+    # variant independence over the whole batch
+    for R, nrm in ((1, 4), (4, 1)):
+        eng.set_variant(R, 8)
+        eng.set_rescale_interval(nrm)
+        ll2, g2 = eng.run(P, inds, W, grad=True)
+        np.testing.assert_allclose(ll2.cpu(), ll.cpu(), rtol=1e-11 if dbl else 2e-6)
+        gs = g.double().abs().amax(-1, keepdim=True).clamp_min(1.0)
+        assert float(((g2.double() - g.double()).abs() / gs).max()) < (1e-8 if dbl else 2e-3)
+
+
+def test_cfg2_posterior_identities():
+    """W = 0 at full length: sum_i pi_i dll/dpi_i = 1 and the emission posteriors count the sites."""
+    K, B, S, L = 16, 4, 64, 60_500
+    data, P, eng = _setup(K, B, S, L, 0, True)
+    inds = torch.arange(S, device="cuda")
+    ll, g = eng.run(P, inds, 0, grad=True, dlog=True)  # theta * d ll / d theta
+    pi_sum = g[:, :, 6, :].sum(-1)
+    np.testing.assert_allclose(pi_sum.cpu(), 1.0, rtol=1e-9)
+    n_obs = torch.tensor((data >= 0).sum(1), dtype=torch.float64, device="cuda")
+    gamma = g[:, :, 4, :].sum(-1) + g[:, :, 5, :].sum(-1)  # e * dll/de summed over states and both rows
+    np.testing.assert_allclose(gamma.cpu(), n_obs[None].expand(B, S).cpu(), rtol=1e-9)
+    n_het = torch.tensor((data == 1).sum(1), dtype=torch.float64, device="cuda")
+    np.testing.assert_allclose(g[:, :, 5, :].sum(-1).cpu(), n_het[None].expand(B, S).cpu(), rtol=1e-9, atol=1e-9)
+
+
+def test_split_additivity_and_directional_derivative():
+    from phlash_amd.engine import HipEngine
+
+    K, B, S, L, W = 16, 3, 40, 60_000, 500
+    data, P, eng = _setup(K, B, S, L, W, True)
+    inds = torch.arange(S, device="cuda")
+    full = eng.run(P, inds, 0, grad=False)
+    scored, g = eng.run(P, inds, W, grad=True)
+    prefix = HipEngine(K, np.ascontiguousarray(data[:, :W]), double_precision=True).run(P, inds, 0, grad=False)
+    np.testing.assert_allclose((prefix + scored).cpu(), full.cpu(), rtol=1e-12)
+    # directional derivative (rows b, d, u, v, e0, e1 perturbed multiplicatively; pi row left alone)
+    torch.manual_seed(0)
+    direction = torch.randn_like(P) * P
+    direction[:, :, 6, :] = 0
+    h = 1e-7  # the truncation error of the central difference is ~ h^2 * 1e13 here (checked with the oracle)
+    up = eng.run(P + h * direction, inds, W, grad=False)
+    dn = eng.run(P - h * direction, inds, W, grad=False)
+    fd = (up - dn) / (2 * h)
+    an = (g * direction).sum((-1, -2))
+    np.testing.assert_allclose(an.cpu(), fd.cpu(), rtol=2e-6, atol=1e-3)
+
+
+def test_cfg4_K64_and_cfg5_K32_shapes():
+    """cfg4 (K = 64, 100 particles) and cfg5 (K = 32, 500 particles) with fewer chunks; cfg5's
+    checkpoint store is cut into particle slabs by a small workspace limit."""
+    for K, B, S in ((64, 100, 24), (32, 500, 12)):
+        data, P, eng = _setup(K, B, S, 60_000, 500, False)
+        inds = torch.arange(S, device="cuda")
+        if K == 32:
+            eng.set_workspace_limit(2 << 30)
+        ll, g = eng.run(P, inds, 500, grad=True)
+        assert torch.isfinite(ll).all() and torch.isfinite(g).all()
+        sub = [0, B // 2, B - 1]
+        ll_ref, g_ref = cport.batch(P[sub].cpu().numpy(), data, [0, S - 1], 500)
+        np.testing.assert_allclose(ll[sub][:, [0, S - 1]].cpu().numpy(), ll_ref, rtol=1e-5)
+        gg = g[sub][:, [0, S - 1]].double().cpu().numpy()
+        scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+        assert (np.abs(gg - g_ref) / scale).max() < 2e-3
+        if K == 32:
+            assert eng.workspace_bytes() < (3 << 30)
