@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one pass of the hot path over one batch: B particles (unconstrained vectors on the
-GPU) -> PSMCParams for every particle (torch float64 on the GPU) -> HIP forward + checkpointed
+GPU) -> PSMCParams for every particle (HIP kernel, float64, with Jacobian) -> HIP forward + checkpointed
 backward kernels over all B x S (particle, chunk) sequences -> sum over chunks -> ONE all-reduce of
 [B, 1 + 7K] across ranks (N > 1) -> chain rule to particle space -> SVGD/AMSGrad update.
 Work per step = B * S * L scored site.particles per GPU (the W warm-up sites of every chunk are
@@ -100,6 +100,7 @@ def main():
     from phlash_amd import parallel, svgd
     from phlash_amd.kernel import get_kernel
     from phlash_amd.model import log_prior
+    from phlash_amd.param_map import particles_to_psmc
     from phlash_amd.params import PSMCParams
     from phlash_amd.synth import particle_population, simulate_chunks
 
@@ -119,7 +120,7 @@ def main():
     def one_step(state):
         xs = state.particles.detach().requires_grad_(True)
         mcp = template.from_flat(xs)
-        pp = PSMCParams.from_dm(mcp.to_dm())
+        pp = particles_to_psmc(template, xs)  # HIP: particle -> PSMCParams (+ Jacobian), one launch
         l2 = parallel.sharded_loglik_sum(kern, pp, inds)  # HIP kernels + the one all-reduce
         lp = log_prior(mcp) + c1 * l2
         (g,) = torch.autograd.grad(lp.sum(), xs)
@@ -212,7 +213,7 @@ def main():
             with torch.no_grad():
                 mcp = template.from_flat(x0.to(dev))
                 pp0 = PSMCParams.from_dm(mcp.to_dm())
-                nb = min(B, 16)  # bounded sample of the particles for the CPU leg
+                nb = B  # the CPU leg bounds its own sample (chunks) to ~cpu-seconds of work
                 ll_gpu, _ = kern.value_and_grad(PSMCParams(*(f[:nb] for f in pp0)), inds, reduce_chunks=False)
             P = pp0.stack().cpu().numpy()[:nb, None]
             cb, rel = cpu_baseline(P, data, W, L, a.cpu_seconds, ll_gpu.cpu().numpy())

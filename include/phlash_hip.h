@@ -76,6 +76,19 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
                const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad,
                int grad_dlog, void* stream);
 
+/* Particle -> PSMCParams for a whole population in one launch, float64, with its Jacobian.
+ * Replaces, for B particles at once: MCMCParams.to_dm (src/phlash/params.py:94-127),
+ * SizeHistory.ect / .pi (src/phlash/size_history.py:123-138,170-193), transition_matrix + _expQ
+ * (src/phlash/transition.py:9-85) and PSMCParams.from_dm (src/phlash/params.py:33-55), which the
+ * reference evaluates per particle under vmap and differentiates with jax.grad.
+ *   K                 hidden states (3..64); P epochs; epoch_of_state[K] (host) maps each state to its
+ *                     epoch (the expansion of the PSMC pattern, src/phlash/util.py:35-37)
+ *   x        device   [B, P+3] = t_tr(2), c_tr(P), rho_over_theta_tr  (ravel order of params.py:58-66)
+ *   params   device   [B, 7, K] rows b,d,u,v,emis0,emis1,pi
+ *   jac      device   [B, 7*K, P+3] d params / d x, or NULL */
+int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x,
+                  int64_t B, double* params, double* jac, void* stream);
+
 /* Tuning / introspection (no reference counterpart).
  * R = lanes per sequence (1,2,4,8,16; must divide K, K/R <= 16), T = checkpoint block (8, or 16
  * where K/R <= 4).

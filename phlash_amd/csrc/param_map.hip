@@ -1,0 +1,253 @@
+// Particle -> PSMCParams on the device, with its Jacobian, in ONE launch.
+//
+// What is computed (reference: jthlab/phlash v1.0.6, paths relative to that repo):
+//   src/phlash/params.py:94-127   MCMCParams.to_dm      x = [t_tr(2), c_tr(P), rho_over_theta_tr]
+//                                  -> t = [0, geomspace(t1, tM, K-1)], c = pattern(softplus(c_tr)),
+//                                     rho = (0.1 + 9.9 sigmoid(.)) theta
+//   src/phlash/size_history.py:17-22,123-138,170-193    _expm1inv, surv, pi, ect
+//   src/phlash/transition.py:9-85                        _expQ (incl. its u<1e-6 branch, quirk Q8),
+//                                                        the running 3x3 products, L / D / U
+//   src/phlash/params.py:33-55    PSMCParams.from_dm     clips, (b, d, u, v) factorisation
+// The reference runs this as ~10^3 XLA ops per particle and differentiates it with jax.grad; the
+// torch restatement in phlash_amd/{params,transition,size_history}.py is ~1,400 kernel launches per
+// SVGD step.  Here one workgroup per particle evaluates the map in float64 with forward-mode dual
+// numbers: thread j carries d/dx_j, every thread carries the value, so the block writes the [7,K]
+// parameter block and its [7K, D] Jacobian (D = P + 3 <= 66) with coalesced stores.  The VJP the
+// sampler needs is then a single batched mat-vec (phlash_amd/param_map.py).
+//
+// Only row 0 of the running 3x3 products is carried (the reference reads nothing else,
+// transition.py:58-71) and the upper triangle is assembled from running products in O(K)
+// (transition.py:76-83 builds it with an O(K^3) masked power).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phk {
+
+constexpr int PM_MAXK = 64;
+
+struct Dual {
+    double v, d;
+};
+__device__ __forceinline__ Dual mk(double v, double d = 0.0) { return Dual{v, d}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return mk(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return mk(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(Dual a) { return mk(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return mk(a.v * b.v, a.d * b.v + a.v * b.d); }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    const double q = a.v / b.v;
+    return mk(q, (a.d - q * b.d) / b.v);
+}
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return mk(a.v + b, a.d); }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return mk(a.v - b, a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return mk(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator*(double b, Dual a) { return mk(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { return mk(a.v / b, a.d / b); }
+__device__ __forceinline__ Dual operator/(double a, Dual b) {
+    const double q = a / b.v;
+    return mk(q, -q * b.d / b.v);
+}
+__device__ __forceinline__ Dual operator-(double a, Dual b) { return mk(a - b.v, -b.d); }
+__device__ __forceinline__ Dual operator+(double a, Dual b) { return mk(a + b.v, b.d); }
+__device__ __forceinline__ Dual dexp(Dual a) {
+    const double e = exp(a.v);
+    return mk(e, e * a.d);
+}
+__device__ __forceinline__ Dual dexpm1(Dual a) { return mk(expm1(a.v), exp(a.v) * a.d); }
+__device__ __forceinline__ Dual dlog(Dual a) { return mk(log(a.v), a.d / a.v); }
+__device__ __forceinline__ Dual dsqrt(Dual a) {
+    const double s = sqrt(a.v);
+    return mk(s, a.d / (2.0 * s));
+}
+// clip with the sub-gradient torch / jax use: 1 inside [lo, hi], 0 outside
+__device__ __forceinline__ Dual dclamp(Dual a, double lo, double hi) {
+    if (a.v < lo) return mk(lo);
+    if (a.v > hi) return mk(hi);
+    return a;
+}
+__device__ __forceinline__ Dual dsoftplus(Dual a) {
+    // log(1 + e^x), threshold 20 as torch.nn.functional.softplus
+    if (a.v > 20.0) return a;
+    const double e = exp(a.v);
+    return mk(log1p(e), a.d * e / (1.0 + e));
+}
+__device__ __forceinline__ Dual dsigmoid(Dual a) {
+    const double s = 1.0 / (1.0 + exp(-a.v));
+    return mk(s, a.d * s * (1.0 - s));
+}
+// 1 / expm1(x), large-x safe  (size_history.py:17-22)
+__device__ __forceinline__ Dual dexpm1inv(Dual x) {
+    if (x.v > 10.0) return -dexp(-x) / dexpm1(-x);
+    return 1.0 / dexpm1(x);
+}
+__device__ __forceinline__ bool is_close0(double a) { return fabs(a) <= 1e-8; }  // isclose(a, 0): atol 1e-8
+
+struct Row3 {
+    Dual r0, r1, r2;
+};
+
+// row <- row @ expQ(r, c, n = 2)   (transition.py:9-34; only the row-vector product is needed)
+__device__ __forceinline__ Row3 step_expQ(Row3 row, Dual r, Dual c) {
+    const double n = 2.0;
+    const Dual cn = c * n;
+    const Dual u = dsqrt(cn * cn - 2.0 * c * (n - 2.0) * r + r * r) / 2.0;
+    const Dual v = (r + cn) / 2.0;
+    const Dual w = (r - cn) / 2.0;
+    const Dual t1 = (dexp(u - v) + dexp(-(u + v))) / 2.0;
+    Dual t2;
+    if (u.v < 1e-6) {
+        // quirk Q8: the reference's series branch is evaluated at u_safe = 1 (transition.py:18-21)
+        t2 = dexp(-v) * (1.0 + 1.0 / 6.0);
+    } else {
+        t2 = (dexp(u - v) - dexp(-(u + v))) / 2.0 / u;
+    }
+    const Dual P11 = t1 - w * t2, P12 = r * t2, P21 = c * t2, P22 = t1 + w * t2;
+    const Dual P13 = 1.0 - P11 - P12, P23 = 1.0 - P21 - P22;
+    Row3 o;
+    o.r0 = row.r0 * P11 + row.r1 * P21;
+    o.r1 = row.r0 * P12 + row.r1 * P22;
+    o.r2 = row.r0 * P13 + row.r1 * P23 + row.r2;
+    return o;
+}
+
+struct PMArgs {
+    int K, P, D;
+    double theta;
+    int8_t epoch[PM_MAXK];  // epoch index of every hidden state (pattern expansion, util.py:35-37)
+    const double* x;        // [B, D]
+    double* params;         // [B, 7, K]
+    double* jac;            // [B, 7K, D] or null
+    int64_t B;
+};
+
+__global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
+    const int K = A.K, D = A.D;
+    const int64_t bidx = blockIdx.x;
+    const int j = threadIdx.x;  // tangent carried by this thread (threads >= D carry a zero tangent)
+    const double* x = A.x + bidx * D;
+    auto X = [&](int i) { return mk(x[i], i == j ? 1.0 : 0.0); };
+
+    // ---- MCMCParams.to_dm (params.py:94-127) -------------------------------------------------
+    const Dual t1 = dexp(X(0));
+    const Dual tM = t1 + dexp(X(1));
+    const Dual lt1 = dlog(t1), ltM = dlog(tM);
+    Dual t[PM_MAXK], c[PM_MAXK];
+    t[0] = mk(0.0);
+    for (int k = 0; k < K - 1; ++k) t[k + 1] = dexp(lt1 + (ltM - lt1) * ((double)k / (double)(K - 2)));
+    for (int k = 0; k < K; ++k) c[k] = dsoftplus(X(2 + A.epoch[k]));
+    const Dual rho = (0.1 + 9.9 * dsigmoid(X(2 + A.P))) * A.theta;
+
+    // ---- SizeHistory.ect (size_history.py:170-193) -------------------------------------------
+    Dual ect[PM_MAXK];
+    for (int k = 0; k < K - 1; ++k) {
+        const Dual dt = t[k + 1] - t[k];
+        Dual e;
+        if (is_close0(c[k].v)) e = (t[k] + t[k + 1]) / 2.0;
+        else if (isinf(c[k].v) || c[k].v > 100.0) e = t[k];
+        else e = 1.0 / c[k] + t[k] - dt * dexpm1inv(c[k] * dt);
+        ect[k] = e;
+    }
+    ect[K - 1] = t[K - 1] + 1.0 / c[K - 1];
+    for (int k = 0; k < K; ++k)
+        if (ect[k].v < 1e-20) ect[k] = mk(1e-20);
+
+    const double lo = 1e-20, hi = 1.0 - 1e-20;
+    double* out = A.params + bidx * 7 * K;
+    double* jac = A.jac ? A.jac + bidx * 7 * K * D : nullptr;
+    auto put = [&](int row, int k, Dual val) {
+        if (j == 0) out[row * K + k] = val.v;
+        if (jac && j < D) jac[(size_t)(row * K + k) * D + j] = val.d;
+    };
+
+    // ---- emissions and pi (params.py:36-43, size_history.py:123-138) --------------------------
+    for (int k = 0; k < K; ++k) {
+        const Dual uu = ect[k] * A.theta;
+        put(4, k, dclamp(dexp(-uu), lo, hi));
+        put(5, k, dclamp(-dexpm1(-uu), lo, hi));
+    }
+    {
+        Dual H = mk(0.0), Sprev = mk(1.0), csum = mk(0.0);
+        Dual Ci[PM_MAXK];
+        for (int k = 0; k < K - 1; ++k) {
+            H = H + c[k] * (t[k + 1] - t[k]);
+            const Dual S = dexp(-H);
+            if (k > 0) {
+                Ci[k - 1] = Sprev - S;
+                csum = csum + Ci[k - 1];
+            }
+            Sprev = S;
+        }
+        Ci[K - 2] = Sprev;  // surv[K-2] - 0
+        csum = csum + Ci[K - 2];
+        put(6, 0, dclamp(1.0 - csum, lo, hi));
+        for (int k = 1; k < K; ++k) put(6, k, dclamp(Ci[k - 1], lo, hi));
+    }
+
+    // ---- transition factors (transition.py:37-83), row 0 of the running products --------------
+    // augmented grid [t0, e0, t1, e1, ...]; state at t_k is Rt[k], at ect_k is Re[k]
+    Row3 row{mk(1.0), mk(0.0), mk(0.0)};
+    Dual Rt2_prev = mk(0.0);  // Rt[k][2]
+    Dual lower[PM_MAXK], diag[PM_MAXK], p1[PM_MAXK], p2[PM_MAXK], p3[PM_MAXK];
+    for (int k = 0; k < K; ++k) {
+        // t_k -> ect_k with rate c_k
+        {
+            const Dual dt = ect[k] - t[k];
+            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * c[k]);
+        }
+        const Row3 Re = row;
+        const Dual c_adj = c[k];  // c * (n - 1), n = 2
+        Dual q, keep;
+        if (k < K - 1) {
+            const Dual gap = (t[k + 1] - ect[k]) * c_adj;
+            q = -dexpm1(-gap);
+            keep = dexp(-gap);
+            const Dual dtk = t[k + 1] - t[k];
+            p2[k] = dclamp(dexp(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
+            p3[k] = dclamp(-dexpm1(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
+        } else {
+            q = mk(1.0);
+            keep = mk(0.0);
+            p2[k] = mk(1e-8);
+            p3[k] = mk(1.0 - 1e-8);
+        }
+        diag[k] = Re.r0 + Re.r1 * q + Re.r2 - Rt2_prev;  // transition.py:60-67
+        p1[k] = dclamp(Re.r1 * keep, 1e-8, 1.0 - 1e-8);
+        // ect_k -> t_{k+1} with rate c_k (the last interval ends in the absorbing Pinf)
+        if (k < K - 1) {
+            const Dual dt = t[k + 1] - ect[k];
+            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * c[k]);
+            lower[k] = row.r2 - Rt2_prev;  // transition.py:58
+            Rt2_prev = row.r2;
+        }
+    }
+
+    // ---- (b, d, u, v) of params.py:44-55 --------------------------------------------------------
+    for (int k = 0; k < K; ++k) {
+        put(0, k, k < K - 1 ? dclamp(lower[k], lo, hi) : mk(0.0));
+        put(1, k, dclamp(diag[k], lo, hi));
+    }
+    {
+        // first row above the diagonal A[0][jj] = p1[0] * prod_{0<l<jj} p2[l] * p3[jj]
+        Dual cum = mk(1.0), A01 = mk(1.0), vprev = mk(0.0);
+        put(3, 0, mk(0.0));
+        for (int jj = 1; jj < K; ++jj) {
+            const Dual A0j = dclamp(p1[0] * cum * p3[jj], lo, hi);
+            if (jj == 1) A01 = A0j;
+            const Dual vj = A0j / A01;
+            put(3, jj, vj);
+            // u[jj-1] = A[jj-1][jj] / v[jj],  A[i][i+1] = p1[i] * p3[i+1]
+            put(2, jj - 1, dclamp(p1[jj - 1] * p3[jj], lo, hi) / vj);
+            cum = cum * p2[jj];
+            vprev = vj;
+        }
+        (void)vprev;
+        put(2, K - 1, mk(0.0));
+    }
+}
+
+hipError_t launch_param_map(const PMArgs& a, hipStream_t st) {
+    if (a.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(param_map_kernel, dim3((unsigned)a.B), dim3(a.D <= 64 ? 64 : 128), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace phk

@@ -22,6 +22,18 @@ namespace phk {
 PHK_DECL(f32_4) PHK_DECL(f32_8) PHK_DECL(f32_16) PHK_DECL(f32_32) PHK_DECL(f32_64)
 PHK_DECL(f64_4) PHK_DECL(f64_8) PHK_DECL(f64_16) PHK_DECL(f64_32) PHK_DECL(f64_64)
 #undef PHK_DECL
+
+constexpr int PM_MAXK = 64;
+struct PMArgs {  // must match param_map.hip
+    int K, P, D;
+    double theta;
+    int8_t epoch[PM_MAXK];
+    const double* x;
+    double* params;
+    double* jac;
+    int64_t B;
+};
+hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
 }  // namespace phk
 
 namespace {
@@ -296,6 +308,31 @@ int phk_timing_totals(phk_handle* h, double* fwd_ms, double* bwd_ms, int* n_laun
     if (n_launches) *n_launches = h->n_launches;
     h->n_launches = 0;  // events are recycled from here on
     h->n_last = 0;
+    return PHK_OK;
+}
+
+int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x, int64_t B,
+                  double* params, double* jac, void* stream) {
+    if (K < 3 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [3, %d]", K, phk::PM_MAXK);
+    if (P < 1 || P > K) return fail(PHK_EINVAL, "P=%d epochs for K=%d states", P, K);
+    if (!epoch_of_state || !x || !params) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0) return fail(PHK_EINVAL, "B must be >= 0");
+    phk::PMArgs a;
+    a.K = K;
+    a.P = P;
+    a.D = P + 3;
+    a.theta = theta;
+    for (int k = 0; k < K; ++k) {
+        if (epoch_of_state[k] < 0 || epoch_of_state[k] >= P) return fail(PHK_EINVAL, "epoch_of_state[%d] = %d outside [0, %d)", k, epoch_of_state[k], P);
+        a.epoch[k] = (int8_t)epoch_of_state[k];
+    }
+    a.x = x;
+    a.params = params;
+    a.jac = jac;
+    a.B = B;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_param_map(a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "param_map kernel launch: %s", hipGetErrorString(e));
     return PHK_OK;
 }
 

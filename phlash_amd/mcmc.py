@@ -25,7 +25,8 @@ from .afs import bws_transform, fold_transform
 from .data import init_mcmc_data
 from .kernel import get_kernel
 from .model import afs_term, log_prior
-from .params import MCMCParams, PSMCParams
+from .param_map import particles_to_psmc
+from .params import MCMCParams
 from .size_history import DemographicModel, SizeHistory
 from .util import Pattern
 
@@ -36,11 +37,10 @@ def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, a
     """[B] log densities of the particles x [B, D] (model.py:24-73 batched; the HMM term is summed
     over every rank's share of the minibatch)."""
     mcp = template.from_flat(x)
-    dm = mcp.to_dm()
-    pp = PSMCParams.from_dm(dm)
+    pp = particles_to_psmc(template, x)  # HIP: to_dm + from_dm for the whole population, one launch
     l1 = log_prior(mcp)
     l2 = parallel.sharded_loglik_sum(kern, pp, local_inds).to(x.device)
-    l3 = afs_term(dm, afs, afs_transform) if afs is not None and len(afs) > 1 else torch.zeros_like(l1)
+    l3 = afs_term(mcp.to_dm(), afs, afs_transform) if afs is not None and len(afs) > 1 else torch.zeros_like(l1)
     ret = c[0] * l1 + c[1] * l2 + c[2] * l3
     return torch.where(torch.isfinite(ret), ret, torch.full_like(ret, -float("inf")))
 

@@ -189,3 +189,30 @@ def test_fit_moves_toward_truth():
                          minibatch_size=8, progress=False, callback=lambda dm: seen.append(float(dm.eta.c.mean())))
     assert len(res) == 16 and len(seen) == 30
     assert all(np.isfinite(seen))
+
+
+@pytest.mark.parametrize("K,pattern", [(16, "14*1+1*2"), (16, "16*1"), (32, "30*1+1*2"), (64, "4+25*2+4+6"), (8, "2*1+3*2")])
+def test_param_map_kernel_vs_torch_definition(K, pattern, rng):
+    """phk_param_map (one launch, dual numbers) == the torch restatement of
+    MCMCParams.to_dm + PSMCParams.from_dm (which tests/test_host_math.py pins to the oracle), values
+    and vector-Jacobian products, for wide particle populations (sigma = 1 as mcmc.py:186-195)."""
+    from phlash_amd.param_map import particles_to_params
+    from phlash_amd.params import MCMCParams, PSMCParams
+    from phlash_amd.util import Pattern
+
+    P = len(Pattern(pattern))
+    assert Pattern(pattern).M == K
+    init = MCMCParams.from_linear(pattern, 1e-4, 15.0, np.ones(P), 1e-2, 2e-2)
+    x = (init.flat[None] + torch.tensor(rng.normal(size=(64, P + 3)))).cuda()
+    xa = x.clone().requires_grad_(True)
+    got = particles_to_params(init, xa)
+    xb = x.clone().requires_grad_(True)
+    want = PSMCParams.from_dm(init.from_flat(xb).to_dm()).stack()
+    np.testing.assert_allclose(got.detach().cpu(), want.detach().cpu(), rtol=1e-9, atol=1e-15)  # sub-diagonal entries are differences of O(1) numbers
+    cot = torch.tensor(rng.normal(size=tuple(want.shape)), device="cuda")
+    (ga,) = torch.autograd.grad((got * cot).sum(), xa)
+    (gb,) = torch.autograd.grad((want * cot).sum(), xb)
+    scale = gb.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+    assert float(((ga - gb).abs() / scale).max()) < 1e-8
+    # no-grad call allocates no Jacobian and gives the same values
+    np.testing.assert_array_equal(particles_to_params(init, x).cpu(), got.detach().cpu())
