@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
     ap.add_argument("--variant", default="", help="R:T override for the kernel variant (dev)")
+    ap.add_argument("--nrm", type=int, default=0, help="rescale interval override (dev; 0 = library default)")
     return ap.parse_args()
 
 
@@ -112,6 +113,8 @@ def main():
     if a.variant:
         r, t = (int(v) for v in a.variant.split(":"))
         kern._eng.set_variant(r, t)
+    if a.nrm:
+        kern._eng.set_rescale_interval(a.nrm)
     kern._eng.set_profiling(True)
     inds = torch.arange(S, device=dev)
     state = svgd.init(x0.to(dev))
