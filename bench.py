@@ -94,9 +94,11 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun: init even at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
     from phlash_amd import parallel, svgd
     from phlash_amd.kernel import get_kernel
@@ -130,7 +132,7 @@ def main():
         return svgd.step(state, g, lr=0.1)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +147,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP events recorded around the kernels on their launch stream, resolved once, after the loop
     fwd_ms, bwd_ms, _n = kern._eng.timing_totals()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
@@ -224,7 +226,7 @@ def main():
             out["parity"] = {"max_rel_err_loglik_vs_f64_oracle": rel, "bar": 1e-5,
                              "sample": cb["sample"].split(",")[0]}
         print(json.dumps(out, ensure_ascii=False), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
