@@ -95,6 +95,11 @@ int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, doubl
  * 0 = choose automatically from B*S. */
 int phk_set_variant(phk_handle* h, int R, int T);
 int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T);
+/* With autotuning on (default; environment PHK_AUTOTUNE=0 turns it off) the first phk_loglik for a
+ * new batch shape times every compiled (R, T) on the first 2,048 sites of that batch (scratch
+ * outputs, a few tens of ms, synchronises the stream once) and keeps the fastest; otherwise a
+ * static rule picks R from the sequence count. */
+int phk_set_autotune(phk_handle* h, int on);
 /* The scaled forward state is brought back to [0.5,1) by an exact power of two after every nrm-th
  * site (1, 2 or 4; 0 = library default).  nrm = 1 is the reference's per-site normalisation
  * (hmm.py:77-79); larger intervals do the same arithmetic with fewer rescales and are safe while

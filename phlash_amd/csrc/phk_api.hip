@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -90,7 +92,11 @@ struct phk_handle {
     int K = 0, device = 0, dbl = 0;
     int64_t N = 0, L = 0, Lw = 0;
     uint32_t* packed = nullptr;
-    DevBuf ckpt, aux, gacc;
+    DevBuf ckpt, aux, gacc, tune_ll, tune_grad;
+    int64_t last_total = -1;  // B*S of the last phk_loglik and the variant it ran with
+    int last_R = 0, last_T = 0;
+    int autotune = 1;                                               // time the candidate variants once per batch shape
+    std::map<std::pair<int64_t, int>, std::pair<int, int>> tuned;   // (sequences per launch, grad?) -> (R, T)
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int profiling = 0;
@@ -108,8 +114,16 @@ size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
 // T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
 bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
 
-void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T) {
+void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T, int want_grad = 1) {
     int r = h->force_R, t = h->force_T;
+    if (!r && !t) {
+        auto it = h->tuned.find({nseq, want_grad});
+        if (it != h->tuned.end()) {
+            *R = it->second.first;
+            *T = it->second.second;
+            return;
+        }
+    }
     if (!t) t = 8;
     if (!r) {
         // smallest R (fewest cross-lane steps, fewest instructions per site.particle) that still
@@ -142,6 +156,54 @@ bool pick_launchers(const phk_handle* h, fwd_fn* f, bwd_fn* b) {
     }
 #undef PHK_CASE
     return false;
+}
+
+// Time every compiled (R, T) on the first `tune_sites` sites of this very batch (scratch outputs)
+// and remember the fastest for this (sequence count, gradient?) shape.  One-off, a few tens of ms.
+int autotune_variant(phk_handle* h, const phk::KArgs& proto, bool want_grad, fwd_fn lf, bwd_fn lb, hipStream_t st) {
+    const int K = h->K;
+    const size_t rs = real_size(h);
+    const int64_t nseq = proto.B * proto.S;
+    const int64_t tune_sites = std::min<int64_t>(h->L, 2048);
+    int rc;
+    if ((rc = h->tune_ll.ensure((size_t)nseq * sizeof(double))) != PHK_OK) return rc;
+    if (want_grad && (rc = h->tune_grad.ensure((size_t)nseq * 7 * K * rs)) != PHK_OK) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 0.f;
+    int bestR = 0, bestT = 0;
+    for (int R = 1; R <= 16; R <<= 1) {
+        if (!valid_R(K, R)) continue;
+        for (int T = 8; T <= 16; T += 8) {
+            if (!valid_T(K, R, T)) continue;
+            phk::KArgs a = proto;
+            a.Ltot = tune_sites;
+            a.W = std::min<int64_t>(proto.W, tune_sites);
+            a.ll = (double*)h->tune_ll.p;
+            a.grad = want_grad ? h->tune_grad.p : nullptr;
+            float ms = 0.f;
+            for (int rep = 0; rep < 2; ++rep) {  // rep 0 loads the code object / warms the caches
+                if (want_grad && !h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
+                HIP_TRY(hipEventRecord(e0, st));
+                hipError_t e = lf(R, T, h->nrm, want_grad, a, 256, st);
+                if (e == hipSuccess && want_grad) e = lb(R, T, h->nrm, a, 256, st);
+                if (e != hipSuccess) return fail(PHK_EHIP, "autotune launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
+                HIP_TRY(hipEventRecord(e1, st));
+                HIP_TRY(hipEventSynchronize(e1));
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            }
+            if (!bestR || ms < best) {
+                best = ms;
+                bestR = R;
+                bestT = T;
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (bestR) h->tuned[{nseq, want_grad ? 1 : 0}] = {bestR, bestT};
+    return PHK_OK;
 }
 
 }  // namespace
@@ -189,6 +251,7 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) h->ws_limit = (int64_t)(free_b / 2);
     else h->ws_limit = (int64_t)32 << 30;
+    if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
 
     int rc = PHK_OK;
     int8_t* staged = nullptr;
@@ -230,6 +293,8 @@ int phk_destroy(phk_handle* h) {
     h->ckpt.release();
     h->aux.release();
     h->gacc.release();
+    h->tune_ll.release();
+    h->tune_grad.release();
     if (h->packed) (void)hipFree(h->packed);
     delete h;
     return PHK_OK;
@@ -245,6 +310,13 @@ int phk_set_variant(phk_handle* h, int R, int T) {
     return PHK_OK;
 }
 
+int phk_set_autotune(phk_handle* h, int on) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    h->autotune = on ? 1 : 0;
+    if (!on) h->tuned.clear();
+    return PHK_OK;
+}
+
 int phk_set_rescale_interval(phk_handle* h, int nrm) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (nrm == 0) nrm = DEFAULT_NRM;
@@ -255,6 +327,11 @@ int phk_set_rescale_interval(phk_handle* h, int nrm) {
 
 int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T) {
     if (!h || !R || !T) return fail(PHK_EINVAL, "NULL argument");
+    if (B * S == h->last_total && h->last_R) {  // what the last call of this shape actually ran (slabs included)
+        *R = h->last_R;
+        *T = h->last_T;
+        return PHK_OK;
+    }
     choose_variant(h, B * S, R, T);
     return PHK_OK;
 }
@@ -354,17 +431,13 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     h->n_last = 0;
     if (h->n_launches > 4096) h->n_launches = 0;  // nobody is collecting: recycle the event pool
 
-    int R = 1, T = 8;
-    choose_variant(h, B * S, &R, &T);
-    if (!valid_R(K, R)) return fail(PHK_EINVAL, "no valid lanes-per-sequence for K=%d", K);
-    if (!valid_T(K, R, T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, T, K);
     const int nt_b = 256, nt_f = 256;
 
-    // slab the (particle, chunk) grid so that the checkpoint store stays under the workspace limit
-    const int64_t nblk = (h->L + T - 1) / T;
+    // slab the (particle, chunk) grid so that the checkpoint store (sized for T = 8, the densest
+    // spacing) stays under the workspace limit
     int64_t Bs = B, Ss = S;
     if (want_grad) {
-        const int64_t per_seq = nblk * K * (int64_t)rs;
+        const int64_t per_seq = ((h->L + 7) / 8) * K * (int64_t)rs;
         int64_t max_seq = std::max<int64_t>(1, h->ws_limit / std::max<int64_t>(per_seq, 1));
         if (B * S > max_seq) {
             if (max_seq >= S) {
@@ -380,6 +453,38 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         if ((rc = h->aux.ensure((size_t)slab * sizeof(phk::SeqAux))) != PHK_OK) return rc;
         if (!h->dbl && (rc = h->gacc.ensure((size_t)slab * 6 * K * sizeof(double))) != PHK_OK) return rc;
     }
+
+    // kernel variant for this launch shape: forced, tuned earlier, tuned now, or the static rule
+    const int64_t nseq_launch = std::min(Bs, B) * std::min(Ss, S);
+    if (h->autotune && !h->force_R && !h->force_T && h->L >= 512 && nseq_launch >= 64 &&
+        !h->tuned.count({nseq_launch, want_grad ? 1 : 0})) {
+        phk::KArgs a;
+        a.packed = h->packed;
+        a.Lw = h->Lw;
+        a.Ltot = h->L;
+        a.W = W;
+        a.inds = inds;
+        a.params = params;
+        a.pstride_b = pstride_b;
+        a.pstride_s = pstride_s;
+        a.B = std::min(Bs, B);
+        a.S = std::min(Ss, S);
+        a.ll = nullptr;
+        a.ckpt = want_grad ? h->ckpt.p : nullptr;
+        a.aux = (phk::SeqAux*)h->aux.p;
+        a.grad = nullptr;
+        a.gacc = (double*)h->gacc.p;
+        a.grad_dlog = grad_dlog;
+        int rc = autotune_variant(h, a, want_grad, lf, lb, st);
+        if (rc != PHK_OK) return rc;
+    }
+    int R = 1, T = 8;
+    choose_variant(h, nseq_launch, &R, &T, want_grad ? 1 : 0);
+    if (!valid_R(K, R)) return fail(PHK_EINVAL, "no valid lanes-per-sequence for K=%d", K);
+    if (!valid_T(K, R, T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, T, K);
+    h->last_total = B * S;
+    h->last_R = R;
+    h->last_T = T;
 
     for (int64_t b0 = 0; b0 < B; b0 += Bs) {
         const int64_t nb = std::min(Bs, B - b0);

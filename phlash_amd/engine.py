@@ -61,6 +61,9 @@ class HipEngine:
     def set_rescale_interval(self, nrm: int = 0):
         _lib.check(_lib.load().phk_set_rescale_interval(self._h, int(nrm)))
 
+    def set_autotune(self, on: bool):
+        _lib.check(_lib.load().phk_set_autotune(self._h, int(bool(on))))
+
     def get_variant(self, B: int, S: int) -> tuple[int, int]:
         r, t = ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.load().phk_get_variant(self._h, int(B), int(S), ctypes.byref(r), ctypes.byref(t)))

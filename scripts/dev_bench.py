@@ -42,6 +42,17 @@ def main():
     inds = torch.arange(a.S, device="cuda")
     work = a.B * a.S * a.L
     print(f"K={K} B={a.B} S={a.S} L={a.L} W={a.W} dbl={a.dbl} work={work:.3e} site-particles")
+    if a.variants == "auto":
+        for rep in range(a.reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ll, g = eng.run(p, inds, warmup=a.W, grad=True)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            f, b, n = eng.last_timing()
+        print(f"auto -> R,T={eng.get_variant(a.B, a.S)} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall * 1e3:8.2f} ms launches={n} "
+              f"-> {work / ((f + b) * 1e-3):.3e} site-particle/s", flush=True)
+        return
     for v in a.variants.split(","):
         R, T, NRM = (int(x) for x in v.split(":"))
         try:

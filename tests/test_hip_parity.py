@@ -158,6 +158,7 @@ def test_golden_survey_values():
 
 def test_slabbed_workspace_matches(data):
     eng = _engine(16, data, False)
+    eng.set_variant(2, 8)  # bit-for-bit comparison below: pin the variant (autotuning picks per launch shape)
     P = _params(16, 5, 1, seed=2)
     inds = np.arange(10)
     ll, g = _run(eng, P, inds, 50)
@@ -193,3 +194,18 @@ def test_errors(data):
         eng.set_rescale_interval(3)
     with pytest.raises(AssertionError):
         _run(eng, _params(16, 1, 1, 0), np.arange(2), 5000)
+
+
+def test_autotune_picks_a_valid_variant_and_keeps_results(rng):
+    data = (rng.uniform(size=(40, 3000)) < 0.05).astype(np.int8)
+    eng = _engine(16, data, False)
+    P = _params(16, 8, 1, seed=4)
+    inds = np.arange(40)
+    ll, g = _run(eng, P, inds, 100)  # first call tunes for 320 sequences
+    R, T = eng.get_variant(8, 40)
+    assert R in (1, 2, 4, 8, 16) and T in (8, 16)
+    ll_ref, g_ref = cport.batch(P, data, inds, 100)
+    _check(ll, g, ll_ref, g_ref, False)
+    eng.set_autotune(False)
+    ll2, g2 = _run(eng, P, inds, 100)  # static rule
+    _check(ll2, g2, ll_ref, g_ref, False)
