@@ -42,7 +42,7 @@
 namespace phk {
 
 constexpr int NT_MAX = 256;        // max threads per workgroup (4 waves); the launch picks <= this
-constexpr int FLUSH_SITES = 512;   // f32 gradient partial sums are folded into f64 this often
+constexpr int FLUSH_SITES = 2048;  // f32 gradient partial sums are folded into f64 this often
 
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
@@ -55,15 +55,16 @@ __device__ __forceinline__ float ldexp_(float x, int e) { return __builtin_ldexp
 __device__ __forceinline__ double ldexp_(double x, int e) { return __builtin_ldexp(x, e); }
 
 // DPP move with zero fill for lanes whose source is outside the 16-lane row.
-template <int CTRL>
+// BANKS: 4-bit mask over the four 4-lane banks of a row; lanes of a disabled bank also get zero.
+template <int CTRL, int BANKS = 0xf>
 __device__ __forceinline__ float dpp_(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, BANKS, false));
 }
-template <int CTRL>
+template <int CTRL, int BANKS = 0xf>
 __device__ __forceinline__ double dpp_(double x) {
     const uint64_t u = __builtin_bit_cast(uint64_t, x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, BANKS, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, BANKS, false);
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
@@ -78,16 +79,18 @@ constexpr int ROW_HALF_MIRROR = 0x141;
 // ---------------------------------------------------------------------------------------------
 template <typename real, int R>
 struct Group {
-    real up1, up2, up4, up8;  // 1.0 where rank >= n, else 0.0
-    real dn1, dn2, dn4, dn8;  // 1.0 where rank + n < R, else 0.0
+    real up1, up2, up3, up4, up8;  // 1.0 where rank >= n, else 0.0
+    real dn1, dn2, dn3, dn4, dn8;  // 1.0 where rank + n < R, else 0.0
 
     __device__ __forceinline__ void init(int rank) {
         up1 = rank >= 1 ? real(1) : real(0);
         up2 = rank >= 2 ? real(1) : real(0);
+        up3 = rank >= 3 ? real(1) : real(0);
         up4 = rank >= 4 ? real(1) : real(0);
         up8 = rank >= 8 ? real(1) : real(0);
         dn1 = rank + 1 < R ? real(1) : real(0);
         dn2 = rank + 2 < R ? real(1) : real(0);
+        dn3 = rank + 3 < R ? real(1) : real(0);
         dn4 = rank + 4 < R ? real(1) : real(0);
         dn8 = rank + 8 < R ? real(1) : real(0);
     }
@@ -100,25 +103,55 @@ struct Group {
         if constexpr (R >= 16) x = x + dpp_<ROW_MIRROR>(x);
         return x;
     }
-    // exclusive prefix over the group: lane r gets sum of x over lanes < r
+    // exclusive prefix over the group: lane r gets sum of x over lanes < r.
+    //   R = 16: the group is the DPP row, row_shr zero-fills, every step is one v_add_f32_dpp;
+    //   R = 8 : Hillis-Steele; the shift by 4 is masked by the DPP bank mask (lanes 4..7 = banks 1,3);
+    //   R = 4 : the group is one quad: three independent quad_perm gathers, depth 3 instead of 5;
+    //   R = 2 : one masked neighbour read.
     __device__ __forceinline__ real excl_prefix(real x) const {
-        if constexpr (R == 1) return real(0);
-        real y = dpp_<ROW_SHR(1)>(x) * up1;
-        if constexpr (R > 2) y = fma_(dpp_<ROW_SHR(1)>(y), up1, y);
-        if constexpr (R > 3) y = fma_(dpp_<ROW_SHR(2)>(y), up2, y);
-        if constexpr (R > 5) y = fma_(dpp_<ROW_SHR(4)>(y), up4, y);
-        if constexpr (R > 9) y = fma_(dpp_<ROW_SHR(8)>(y), up8, y);
-        return y;
+        if constexpr (R == 1) {
+            return real(0);
+        } else if constexpr (R == 2) {
+            return dpp_<ROW_SHR(1)>(x) * up1;
+        } else if constexpr (R == 4) {
+            real y = dpp_<QP(0, 0, 1, 2)>(x) * up1;
+            y = fma_(dpp_<QP(0, 0, 0, 1)>(x), up2, y);
+            return fma_(dpp_<QP(0, 0, 0, 0)>(x), up3, y);
+        } else if constexpr (R == 8) {
+            real y = dpp_<ROW_SHR(1)>(x) * up1;
+            y = fma_(dpp_<ROW_SHR(1)>(y), up1, y);
+            y = fma_(dpp_<ROW_SHR(2)>(y), up2, y);
+            return y + dpp_<ROW_SHR(4), 0xA>(y);
+        } else {
+            real y = dpp_<ROW_SHR(1)>(x);
+            y = y + dpp_<ROW_SHR(1)>(y);
+            y = y + dpp_<ROW_SHR(2)>(y);
+            y = y + dpp_<ROW_SHR(4)>(y);
+            return y + dpp_<ROW_SHR(8)>(y);
+        }
     }
     // exclusive suffix: lane r gets sum of x over lanes > r
     __device__ __forceinline__ real excl_suffix(real x) const {
-        if constexpr (R == 1) return real(0);
-        real y = dpp_<ROW_SHL(1)>(x) * dn1;
-        if constexpr (R > 2) y = fma_(dpp_<ROW_SHL(1)>(y), dn1, y);
-        if constexpr (R > 3) y = fma_(dpp_<ROW_SHL(2)>(y), dn2, y);
-        if constexpr (R > 5) y = fma_(dpp_<ROW_SHL(4)>(y), dn4, y);
-        if constexpr (R > 9) y = fma_(dpp_<ROW_SHL(8)>(y), dn8, y);
-        return y;
+        if constexpr (R == 1) {
+            return real(0);
+        } else if constexpr (R == 2) {
+            return dpp_<ROW_SHL(1)>(x) * dn1;
+        } else if constexpr (R == 4) {
+            real y = dpp_<QP(1, 2, 3, 3)>(x) * dn1;
+            y = fma_(dpp_<QP(2, 3, 3, 3)>(x), dn2, y);
+            return fma_(dpp_<QP(3, 3, 3, 3)>(x), dn3, y);
+        } else if constexpr (R == 8) {
+            real y = dpp_<ROW_SHL(1)>(x) * dn1;
+            y = fma_(dpp_<ROW_SHL(1)>(y), dn1, y);
+            y = fma_(dpp_<ROW_SHL(2)>(y), dn2, y);
+            return y + dpp_<ROW_SHL(4), 0x5>(y);
+        } else {
+            real y = dpp_<ROW_SHL(1)>(x);
+            y = y + dpp_<ROW_SHL(1)>(y);
+            y = y + dpp_<ROW_SHL(2)>(y);
+            y = y + dpp_<ROW_SHL(4)>(y);
+            return y + dpp_<ROW_SHL(8)>(y);
+        }
     }
 };
 
