@@ -9,8 +9,10 @@ Differences from the reference, all deliberate:
 * random numbers come from numpy/torch generators, not JAX's PRNG: runs are reproducible for a
   given ``key`` (an int seed here) but not bit-identical to a JAX run;
 * SVGD / AMSGrad are the restatements in ``svgd.py`` (parity unpinned, see there);
-* under ``torchrun`` (one process per GPU) the chunk rows are sharded across ranks and each step
-  ends in one all-reduce (``parallel.py``); all ranks return the same particles.
+* under ``torchrun`` (one process per GPU) the work is sharded across ranks -- by chunk rows when the
+  minibatch has at least as many chunks as ranks, otherwise by particles (option ``shard``:
+  "auto" | "chunks" | "particles") -- and each step ends in one all-reduce (``parallel.py``); all
+  ranks return the same particles.
 """
 
 from __future__ import annotations
@@ -33,13 +35,13 @@ from .util import Pattern
 F64 = torch.float64
 
 
-def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, afs_transform):
-    """[B] log densities of the particles x [B, D] (model.py:24-73 batched; the HMM term is summed
-    over every rank's share of the minibatch)."""
+def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, afs_transform, reduce=True):
+    """[B] log densities of the particles x [B, D] (model.py:24-73 batched; with ``reduce`` the HMM
+    term is summed over every rank's share of the minibatch)."""
     mcp = template.from_flat(x)
     pp = particles_to_psmc(template, x)  # HIP: to_dm + from_dm for the whole population, one launch
     l1 = log_prior(mcp)
-    l2 = parallel.sharded_loglik_sum(kern, pp, local_inds).to(x.device)
+    l2 = parallel.sharded_loglik_sum(kern, pp, local_inds, reduce=reduce).to(x.device)
     l3 = afs_term(mcp.to_dm(), afs, afs_transform) if afs is not None and len(afs) > 1 else torch.zeros_like(l1)
     ret = c[0] * l1 + c[1] * l2 + c[2] * l3
     return torch.where(torch.isfinite(ret), ret, torch.full_like(ret, -float("inf")))
@@ -128,10 +130,12 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
 
     # this rank's rows of the chunk matrix; the warm-up columns stay attached (fused, see module doc)
     rank, size = parallel.world()
+    mode = parallel.shard_mode(S, size, options.get("shard", "auto"))
+    by_particles = size > 1 and mode == "particles"
     # the reference asserts that no row of the scored part is entirely missing (gpu.py:111-113 on
     # data_chunks, mcmc.py:203-209)
     assert np.all(chunks[:, overlap:].max(axis=1) > -1), "data contains observations with all missing values"
-    mine = parallel.local_rows(N, rank, size)
+    mine = np.arange(N) if by_particles else parallel.local_rows(N, rank, size)
     train_kern = get_kernel(M=M, data=np.ascontiguousarray(chunks[mine]),
                             double_precision=options.get("double_precision", False), overlap=overlap)
 
@@ -143,13 +147,20 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
         N_test = test_rows.shape[0]
         # reference: warm-up = one all-missing column (mcmc.py:230-233) -> prepend it, overlap = 1
         test_rows = np.concatenate([np.full((N_test, 1), -1, np.int8), test_rows.clip(-1, 1).astype(np.int8)], 1)
-        t_mine = parallel.local_rows(N_test, rank, size)
+        t_mine = np.arange(N_test) if by_particles else parallel.local_rows(N_test, rank, size)
         test_kern = get_kernel(M=M, data=np.ascontiguousarray(test_rows[t_mine]), double_precision=False, overlap=1) \
             if len(t_mine) else None
         c_elpd = torch.tensor([0.0, 1.0, 1.0], dtype=F64, device=dev)
 
         def elpd(xs):
             with torch.no_grad():
+                if by_particles:
+                    idx = torch.arange(rank, xs.shape[0], size, device=xs.device)
+                    tot = torch.zeros(1, dtype=F64, device=xs.device)
+                    if idx.numel():
+                        tot += _log_density_population(xs[idx], template, c_elpd, test_kern, np.arange(N_test),
+                                                       test_afs, afs_transform, reduce=False).sum()
+                    return float(parallel.all_reduce_sum_(tot)) / xs.shape[0]
                 if test_kern is None:  # more ranks than test rows: contribute zeros to the all-reduce
                     k_, li = train_kern, np.zeros(0, np.int64)
                 else:
@@ -181,10 +192,16 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             pass
     for i in it:
         inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
-        local = parallel.split_minibatch(inds, rank, size)
-        xs = state.particles.detach().requires_grad_(True)
-        lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
-        (g,) = torch.autograd.grad(lp.sum(), xs)
+        if by_particles:
+            _, g = parallel.particle_sharded_value_and_grad(
+                lambda xl: _log_density_population(xl, template, c_train, train_kern, inds, afs, afs_transform,
+                                                   reduce=False),
+                state.particles)
+        else:
+            local = parallel.split_minibatch(inds, rank, size)
+            xs = state.particles.detach().requires_grad_(True)
+            lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
+            (g,) = torch.autograd.grad(lp.sum(), xs)
         state = svgd.step(state, g, lr)
         assert bool(torch.isfinite(state.particles).all())  # mcmc.py:281-285
         if elpd is not None and i % 10 == 0:

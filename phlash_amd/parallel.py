@@ -7,6 +7,17 @@ collective anywhere.  Here the (particle x chunk) grid is embarrassingly paralle
 only coupling is the sum over chunks of the per-particle log-likelihood and gradient
 (model.py:57 ``.sum()``), so:
 
+Two ways to cut the (particle x chunk) grid, both ending in exactly one collective per step:
+
+* **chunks** (default when the minibatch has at least as many chunks as there are ranks; the layout
+  BASELINE.json's multi-GPU configs describe) -- see below;
+* **particles** (the reference's production shape is 500 particles x <= 5 chunks, fewer chunks than
+  GPUs): every rank holds all chunk rows, evaluates the particles rank, rank+W, ... and the
+  per-particle values and gradients are assembled with one all-reduce of a zero-padded [B, 1+D]
+  buffer (``particle_sharded_value_and_grad``).
+
+Chunk mode:
+
 * rank r keeps rows r, r+W, r+2W, ... of the chunk matrix on its GPU (no replication);
 * a global minibatch (drawn identically on every rank from a common seed) is split by ownership;
 * every rank evaluates all particles on its chunks and the partial sums [B, 1 + 7K] are combined by
@@ -50,24 +61,51 @@ class _ShardedLogLikSum(torch.autograd.Function):
     [B, 7, K] parameter block -- value and gradient travel in one all-reduce."""
 
     @staticmethod
-    def forward(ctx, params, evaluate, local_inds):
+    def forward(ctx, params, evaluate, local_inds, reduce=True):
         # evaluate(params [B,7,K], local_inds) -> (ll_sum [B] f64, grad_sum [B,7,K] f64), local chunks only
         ll, g = evaluate(params, local_inds)
         B = params.shape[0]
         buf = torch.cat([ll.reshape(B, 1), g.reshape(B, -1)], 1).contiguous()
-        all_reduce_sum_(buf)
+        if reduce:
+            all_reduce_sum_(buf)
         ctx.save_for_backward(buf[:, 1:].reshape(g.shape))
         return buf[:, 0].clone()
 
     @staticmethod
     def backward(ctx, gll):
         (g,) = ctx.saved_tensors
-        return gll[:, None, None] * g, None, None
+        return gll[:, None, None] * g, None, None, None
 
 
-def sharded_loglik_sum(kern, pp, local_inds) -> torch.Tensor:
+def shard_mode(minibatch_size: int, size: int, requested: str = "auto") -> str:
+    """"chunks" or "particles" (see module docstring)."""
+    if requested in ("chunks", "particles"):
+        return requested
+    return "chunks" if minibatch_size >= size else "particles"
+
+
+def particle_sharded_value_and_grad(logp_fn, x: torch.Tensor):
+    """logp_fn(x_local [Bl, D]) -> [Bl] (differentiable).  Every rank evaluates particles
+    rank, rank+W, ...; returns (logp [B], grad [B, D]) identical on all ranks, assembled with ONE
+    all-reduce of a zero-padded [B, 1 + D] buffer."""
+    rank, size = world()
+    B, D = x.shape
+    idx = torch.arange(rank, B, size, device=x.device)
+    xl = x.detach()[idx].requires_grad_(True)
+    buf = torch.zeros((B, 1 + D), dtype=x.dtype, device=x.device)
+    if idx.numel():
+        lp = logp_fn(xl)
+        (g,) = torch.autograd.grad(lp.sum(), xl)
+        buf[idx, 0] = lp.detach()
+        buf[idx, 1:] = g
+    all_reduce_sum_(buf)
+    return buf[:, 0], buf[:, 1:]
+
+
+def sharded_loglik_sum(kern, pp, local_inds, reduce: bool = True) -> torch.Tensor:
     """pp: PSMCParams with fields [B, K] (one block per particle).  Returns [B]: the log-likelihood
-    summed over the chunks of every rank.  ``kern`` holds this rank's rows."""
+    summed over the chunks of every rank (``reduce=False``: of this rank only -- particle mode).
+    ``kern`` holds this rank's rows."""
     from .params import PSMCParams  # noqa: F401  (type only)
 
     params = pp.stack().to(kern.device)
@@ -82,4 +120,4 @@ def sharded_loglik_sum(kern, pp, local_inds) -> torch.Tensor:
             return z, torch.zeros(p.shape, dtype=torch.float64, device=kern.device)
         return kern.value_and_grad(PSMCParams.unstack(p), inds, reduce_chunks=True)
 
-    return _ShardedLogLikSum.apply(params, evaluate, local_inds)
+    return _ShardedLogLikSum.apply(params, evaluate, local_inds, reduce)

@@ -60,6 +60,36 @@ def _worker(rank, size, port, minibatch, out):
         dist.destroy_process_group()
 
 
+def _worker_particles(rank, size, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        from phlash_amd import parallel
+
+        x = torch.tensor(np.random.default_rng(3).normal(size=(5, 4)))
+
+        def logp(xl):  # any per-particle function: rows must come back in place
+            return -(xl**2).sum(1) + xl[:, 0] * xl[:, 1]
+
+        lp, g = parallel.particle_sharded_value_and_grad(logp, x)
+        if rank == 0:
+            torch.save({"lp": lp, "g": g, "x": x}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_particle_sharding(tmp_path):
+    out = str(tmp_path / "p.pt")
+    mp.start_processes(_worker_particles, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out)
+    x = got["x"].clone().requires_grad_(True)
+    lp = -(x**2).sum(1) + x[:, 0] * x[:, 1]
+    (g,) = torch.autograd.grad(lp.sum(), x)
+    np.testing.assert_allclose(got["lp"], lp.detach(), rtol=1e-14)
+    np.testing.assert_allclose(got["g"], g, rtol=1e-14)
+
+
 @pytest.mark.parametrize("minibatch", [[0, 1, 2, 3, 4, 5, 6], [2, 2, 4], [5]])
 def test_sharded_equals_unsharded(tmp_path, minibatch):
     from oracle import cport
@@ -91,3 +121,5 @@ def test_sharding_helpers():
         loc = parallel.split_minibatch(mb, r, 4)
         np.testing.assert_array_equal(rows[r][loc], mb[mb % 4 == r])
     assert parallel.world() == (0, 1)
+    assert parallel.shard_mode(5, 8) == "particles" and parallel.shard_mode(8, 8) == "chunks"
+    assert parallel.shard_mode(500, 8, "particles") == "particles"
