@@ -100,6 +100,17 @@ int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T);
  * outputs, a few tens of ms, synchronises the stream once) and keeps the fastest; otherwise a
  * static rule picks R from the sequence count. */
 int phk_set_autotune(phk_handle* h, int on);
+/* How the gradient is evaluated: 0 = serial (forward kernel, then one backward sweep per sequence:
+ * best when B*S sequences fill the chip), 1 = segmented (forward kernel and an independent
+ * beta-recursion kernel run concurrently on two streams, then every 512-site segment of every
+ * sequence is swept in parallel: best for small batches such as the reference's 500 particles x 5
+ * chunks), -1 = automatic (default; the autotuner times both where the batch is small). */
+int phk_set_backward_mode(phk_handle* h, int mode);
+/* Force a complete plan (segmented = -1 returns to automatic).  Serial: (R, T).  Segmented: R for
+ * the segment sweep, R_forward for the forward kernel, R_scan for the beta scan; T is 8. */
+int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int R_scan);
+/* The plan the last phk_loglik ran with. */
+int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, int* R_scan);
 /* The scaled forward state is brought back to [0.5,1) by an exact power of two after every nrm-th
  * site (1, 2 or 4; 0 = library default).  nrm = 1 is the reference's per-site normalisation
  * (hmm.py:77-79); larger intervals do the same arithmetic with fewer rescales and are safe while

@@ -30,6 +30,9 @@ SIGNATURES = {
     "phk_get_variant": (_i, [_vp, _i64, _i64, _ip, _ip]),
     "phk_set_rescale_interval": (_i, [_vp, _i]),
     "phk_set_autotune": (_i, [_vp, _i]),
+    "phk_set_backward_mode": (_i, [_vp, _i]),
+    "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "phk_get_plan": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "phk_set_workspace_limit": (_i, [_vp, _i64]),
     "phk_workspace_bytes": (_i64, [_vp]),
     "phk_set_profiling": (_i, [_vp, _i]),

@@ -34,11 +34,26 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
 }
 
 template <int R, int T, int NRM>
-static hipError_t bwd_rtn(const KArgs& a, int nt, hipStream_t st) {
+static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
+    const int64_t nseq = a.B * a.S;
+    const int spb = nt / R;
+    const dim3 block(nt);
+    if (units <= 0) {  // one serial sweep per sequence
+        const dim3 grid((unsigned)((nseq + spb - 1) / spb));
+        hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds_bytes(R, nt), st, a);
+    } else {  // `units` independent segments per sequence
+        const dim3 grid((unsigned)((nseq + spb - 1) / spb), (unsigned)units);
+        hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds_bytes(R, nt), st, a);
+    }
+    return hipGetLastError();
+}
+
+template <int R, int NRM>
+static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
     const int64_t nseq = a.B * a.S;
     const int spb = nt / R;
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
-    hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM>), grid, block, lds_bytes(R, nt), st, a);
+    hipLaunchKernelGGL((bscan_kernel<real_t, KK, R, NRM>), grid, block, lds_bytes(R, nt), st, a, seg_sites, bseg, fseg);
     return hipGetLastError();
 }
 
@@ -58,13 +73,24 @@ static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t
     }
 }
 template <int R, int T>
-static hipError_t bwd_rt(int nrm, const KArgs& a, int nt, hipStream_t st) {
+static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
     if constexpr (!variant_ok<R, T>()) {
         return hipErrorInvalidValue;
     } else {
-        if (nrm == 1) return bwd_rtn<R, T, 1>(a, nt, st);
-        if (nrm == 2) return bwd_rtn<R, T, 2>(a, nt, st);
-        if (nrm == 4) return bwd_rtn<R, T, 4>(a, nt, st);
+        if (nrm == 1) return bwd_rtn<R, T, 1>(a, units, nt, st);
+        if (nrm == 2) return bwd_rtn<R, T, 2>(a, units, nt, st);
+        if (nrm == 4) return bwd_rtn<R, T, 4>(a, units, nt, st);
+        return hipErrorInvalidValue;
+    }
+}
+template <int R>
+static hipError_t bscan_r(int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
+    if constexpr (!variant_ok<R, 8>()) {
+        return hipErrorInvalidValue;
+    } else {
+        if (nrm == 1) return bscan_rn<R, 1>(a, seg_sites, bseg, fseg, nt, st);
+        if (nrm == 2) return bscan_rn<R, 2>(a, seg_sites, bseg, fseg, nt, st);
+        if (nrm == 4) return bscan_rn<R, 4>(a, seg_sites, bseg, fseg, nt, st);
         return hipErrorInvalidValue;
     }
 }
@@ -76,9 +102,9 @@ static hipError_t fwd_r(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipSt
     return hipErrorInvalidValue;
 }
 template <int R>
-static hipError_t bwd_r(int T, int nrm, const KArgs& a, int nt, hipStream_t st) {
-    if (T == 8) return bwd_rt<R, 8>(nrm, a, nt, st);
-    if (T == 16) return bwd_rt<R, 16>(nrm, a, nt, st);
+static hipError_t bwd_r(int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
+    if (T == 8) return bwd_rt<R, 8>(nrm, a, units, nt, st);
+    if (T == 16) return bwd_rt<R, 16>(nrm, a, units, nt, st);
     return hipErrorInvalidValue;
 }
 
@@ -92,15 +118,31 @@ hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, co
     }
     return hipErrorInvalidValue;
 }
-hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, int nrm, const KArgs& a, int nt, hipStream_t st) {
+hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
     switch (R) {
-        case 1: return bwd_r<1>(T, nrm, a, nt, st);
-        case 2: return bwd_r<2>(T, nrm, a, nt, st);
-        case 4: return bwd_r<4>(T, nrm, a, nt, st);
-        case 8: return bwd_r<8>(T, nrm, a, nt, st);
-        case 16: return bwd_r<16>(T, nrm, a, nt, st);
+        case 1: return bwd_r<1>(T, nrm, a, units, nt, st);
+        case 2: return bwd_r<2>(T, nrm, a, units, nt, st);
+        case 4: return bwd_r<4>(T, nrm, a, units, nt, st);
+        case 8: return bwd_r<8>(T, nrm, a, units, nt, st);
+        case 16: return bwd_r<16>(T, nrm, a, units, nt, st);
     }
     return hipErrorInvalidValue;
+}
+hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg,
+                                              int nt, hipStream_t st) {
+    switch (R) {
+        case 1: return bscan_r<1>(nrm, a, seg_sites, bseg, fseg, nt, st);
+        case 2: return bscan_r<2>(nrm, a, seg_sites, bseg, fseg, nt, st);
+        case 4: return bscan_r<4>(nrm, a, seg_sites, bseg, fseg, nt, st);
+        case 8: return bscan_r<8>(nrm, a, seg_sites, bseg, fseg, nt, st);
+        case 16: return bscan_r<16>(nrm, a, seg_sites, bseg, fseg, nt, st);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t PHK_CAT(launch_finalize_, PHK_SUFFIX)(const KArgs& a, hipStream_t st) {
+    const int64_t n = a.B * a.S * KK;
+    hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, KK);
+    return hipGetLastError();
 }
 
 }  // namespace phk

@@ -18,9 +18,12 @@
 #include "psmc_kernels.hip"
 
 namespace phk {
-#define PHK_DECL(tag)                                                                                 \
-    hipError_t launch_fwd_##tag(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st); \
-    hipError_t launch_bwd_##tag(int R, int T, int nrm, const KArgs& a, int nt, hipStream_t st);
+#define PHK_DECL(tag)                                                                                                  \
+    hipError_t launch_fwd_##tag(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st);              \
+    hipError_t launch_bwd_##tag(int R, int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st);              \
+    hipError_t launch_bscan_##tag(int R, int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, \
+                                  hipStream_t st);                                                                      \
+    hipError_t launch_finalize_##tag(const KArgs& a, hipStream_t st);
 PHK_DECL(f32_4) PHK_DECL(f32_8) PHK_DECL(f32_16) PHK_DECL(f32_32) PHK_DECL(f32_64)
 PHK_DECL(f64_4) PHK_DECL(f64_8) PHK_DECL(f64_16) PHK_DECL(f64_32) PHK_DECL(f64_64)
 #undef PHK_DECL
@@ -58,7 +61,9 @@ int fail(int code, const char* fmt, ...) {
                         hipGetErrorString(e_));                                            \
     } while (0)
 
-constexpr int DEFAULT_NRM = 4;  // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
+constexpr int DEFAULT_NRM = 4;   // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
+constexpr int SEG_BLOCKS = 64;   // blocks per segment of the segmented backward (512 sites at T = 8)
+constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 
 struct DevBuf {
     void* p = nullptr;
@@ -86,70 +91,61 @@ struct DevBuf {
     }
 };
 
+// How one launch shape is evaluated.
+//   serial   : forward kernel (R, T) -> backward kernel (R, T), one sweep per sequence.  Large batches.
+//   segmented: forward kernel (R1, T) on the call's stream || beta scan (R2) on a second stream ->
+//              backward kernel (R3, T) over independent segments -> finalize.  Small batches, where
+//              a serial sweep leaves most of the chip idle.
+struct Plan {
+    int segmented = 0;
+    int R = 2, T = 8;    // serial: both kernels; segmented: R = R3 of the segment sweep
+    int R1 = 0, R2 = 0;  // segmented: forward kernel / beta scan
+};
+
 }  // namespace
 
 struct phk_handle {
     int K = 0, device = 0, dbl = 0;
     int64_t N = 0, L = 0, Lw = 0;
     uint32_t* packed = nullptr;
-    DevBuf ckpt, aux, gacc, tune_ll, tune_grad;
-    int64_t last_total = -1;  // B*S of the last phk_loglik and the variant it ran with
-    int last_R = 0, last_T = 0;
-    int autotune = 1;                                               // time the candidate variants once per batch shape
-    std::map<std::pair<int64_t, int>, std::pair<int, int>> tuned;   // (sequences per launch, grad?) -> (R, T)
+    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, tune_ll, tune_grad;
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
+    int mode = -1;     // -1 auto, 0 serial, 1 segmented
+    int has_forced_plan = 0;  // phk_set_plan: overrides everything above
+    Plan forced_plan;
+    int autotune = 1;  // time the candidate plans once per launch shape
+    std::map<std::pair<int64_t, int>, Plan> tuned;  // (sequences per launch, grad?) -> plan
+    int64_t last_total = -1;  // B*S of the last phk_loglik and the plan it ran with
+    Plan last_plan;
+    hipStream_t side = nullptr;  // second stream of the segmented plan
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int profiling = 0;
-    std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch pair since the last timing query
-    int n_launches = 0;          // launch pairs recorded since the last query
+    std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch since the last timing query
+    int n_launches = 0;          // launches recorded since the last query
     int n_last = 0;              // ... of which by the last call
 };
 
 namespace {
 
-bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R <= K && K % R == 0 && K / R <= 16; }
-
-size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
-
-// T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
-bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
-
-void choose_variant(const phk_handle* h, int64_t nseq, int* R, int* T, int want_grad = 1) {
-    int r = h->force_R, t = h->force_T;
-    if (!r && !t) {
-        auto it = h->tuned.find({nseq, want_grad});
-        if (it != h->tuned.end()) {
-            *R = it->second.first;
-            *T = it->second.second;
-            return;
-        }
-    }
-    if (!t) t = 8;
-    if (!r) {
-        // smallest R (fewest cross-lane steps, fewest instructions per site.particle) that still
-        // gives every one of the 1024 SIMDs a wave; otherwise the largest valid R.  Measured at
-        // cfg2 (50,000 sequences, K=16, f32): R=2 3.6e10, R=1 3.2e10, R=4 2.8e10 site.particle/s.
-        int best = 0;
-        for (int c = 1; c <= 16; c <<= 1) {
-            if (!valid_R(h->K, c)) continue;
-            if (!valid_T(h->K, c, t)) continue;
-            best = c;
-            if (nseq * c / 64 >= 1024) break;
-        }
-        r = best ? best : 1;
-    }
-    *R = r;
-    *T = t;
-}
-
 typedef hipError_t (*fwd_fn)(int, int, int, bool, const phk::KArgs&, int, hipStream_t);
-typedef hipError_t (*bwd_fn)(int, int, int, const phk::KArgs&, int, hipStream_t);
+typedef hipError_t (*bwd_fn)(int, int, int, const phk::KArgs&, int, int, hipStream_t);
+typedef hipError_t (*bscan_fn)(int, int, const phk::KArgs&, int64_t, void*, int32_t*, int, hipStream_t);
+typedef hipError_t (*fin_fn)(const phk::KArgs&, hipStream_t);
+struct Launchers {
+    fwd_fn fwd = nullptr;
+    bwd_fn bwd = nullptr;
+    bscan_fn bscan = nullptr;
+    fin_fn fin = nullptr;
+};
 
-bool pick_launchers(const phk_handle* h, fwd_fn* f, bwd_fn* b) {
-#define PHK_CASE(k)                                                        \
-    case k:                                                                \
-        *f = h->dbl ? phk::launch_fwd_f64_##k : phk::launch_fwd_f32_##k;   \
-        *b = h->dbl ? phk::launch_bwd_f64_##k : phk::launch_bwd_f32_##k;   \
+bool pick_launchers(const phk_handle* h, Launchers* l) {
+#define PHK_CASE(k)                                                                    \
+    case k:                                                                            \
+        l->fwd = h->dbl ? phk::launch_fwd_f64_##k : phk::launch_fwd_f32_##k;           \
+        l->bwd = h->dbl ? phk::launch_bwd_f64_##k : phk::launch_bwd_f32_##k;           \
+        l->bscan = h->dbl ? phk::launch_bscan_f64_##k : phk::launch_bscan_f32_##k;     \
+        l->fin = h->dbl ? phk::launch_finalize_f64_##k : phk::launch_finalize_f32_##k; \
         return true;
     switch (h->K) {
         PHK_CASE(4) PHK_CASE(8) PHK_CASE(16) PHK_CASE(32) PHK_CASE(64)
@@ -158,51 +154,220 @@ bool pick_launchers(const phk_handle* h, fwd_fn* f, bwd_fn* b) {
     return false;
 }
 
-// Time every compiled (R, T) on the first `tune_sites` sites of this very batch (scratch outputs)
-// and remember the fastest for this (sequence count, gradient?) shape.  One-off, a few tens of ms.
-int autotune_variant(phk_handle* h, const phk::KArgs& proto, bool want_grad, fwd_fn lf, bwd_fn lb, hipStream_t st) {
+bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R <= K && K % R == 0 && K / R <= 16; }
+// T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
+bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
+size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
+
+// smallest R (fewest instructions per site.particle) that still gives every SIMD `waves` waves
+int throughput_R(const phk_handle* h, int64_t units, int T, int waves) {
+    int best = 0;
+    for (int c = 1; c <= 16; c <<= 1) {
+        if (!valid_R(h->K, c) || !valid_T(h->K, c, T)) continue;
+        best = c;
+        if (units * c / 64 >= 1024 * (int64_t)waves) break;
+    }
+    return best ? best : 1;
+}
+int largest_R(const phk_handle* h, int T) {
+    int best = 1;
+    for (int c = 1; c <= 16; c <<= 1)
+        if (valid_R(h->K, c) && valid_T(h->K, c, T)) best = c;
+    return best;
+}
+
+int64_t n_units(const phk_handle* h, int T, int64_t W) {
+    const int64_t nblk = (h->L + T - 1) / T;
+    const int64_t nseg = (nblk + SEG_BLOCKS - 1) / SEG_BLOCKS;
+    const int64_t segW = W > 0 ? ((W - 1) / T) / SEG_BLOCKS : 0;
+    return nseg - segW;
+}
+
+// the plan when nothing was forced or tuned
+Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
+    Plan p;
+    p.T = h->force_T ? h->force_T : 8;
+    p.R = h->force_R ? h->force_R : throughput_R(h, nseq, p.T, 1);
+    const int64_t units = n_units(h, 8, W);
+    const bool small = nseq * p.R / 64 < 512 && units >= 8;
+    p.segmented = h->mode == 1 || (h->mode < 0 && small && !h->force_R && !h->force_T);
+    if (p.segmented) {
+        p.T = 8;
+        p.R1 = p.R2 = h->force_R ? h->force_R : largest_R(h, 8);
+        p.R = h->force_R ? h->force_R : throughput_R(h, nseq * units, 8, 2);
+    }
+    return p;
+}
+
+Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
+    if (h->has_forced_plan) {
+        Plan p = h->forced_plan;
+        if (!want_grad) {
+            p.R = p.segmented ? p.R1 : p.R;
+            p.segmented = 0;
+        }
+        return p;
+    }
+    if (!h->force_R && !h->force_T && h->mode < 0) {
+        auto it = h->tuned.find({nseq, want_grad});
+        if (it != h->tuned.end()) return it->second;
+    }
+    Plan p = static_plan(h, nseq, W);
+    if (!want_grad) p.segmented = 0;
+    return p;
+}
+
+// scratch shared by both plans, sized for one launch of `nseq` sequences
+int ensure_scratch(phk_handle* h, int64_t nseq) {
+    const int K = h->K;
+    const size_t rs = real_size(h);
+    const int64_t nblk8 = (h->L + 7) / 8;
+    const int64_t nsegp = (nblk8 + SEG_BLOCKS - 1) / SEG_BLOCKS + 1;
+    int rc;
+    if ((rc = h->ckpt.ensure((size_t)nseq * nblk8 * K * rs)) != PHK_OK) return rc;
+    if ((rc = h->aux.ensure((size_t)nseq * sizeof(phk::SeqAux))) != PHK_OK) return rc;
+    if ((rc = h->gacc.ensure((size_t)nseq * 6 * K * sizeof(double))) != PHK_OK) return rc;
+    if ((rc = h->eblk.ensure((size_t)nseq * nblk8 * sizeof(int16_t))) != PHK_OK) return rc;
+    if ((rc = h->eseg.ensure((size_t)nseq * nsegp * sizeof(int32_t))) != PHK_OK) return rc;
+    if ((rc = h->fseg.ensure((size_t)nseq * nsegp * sizeof(int32_t))) != PHK_OK) return rc;
+    if ((rc = h->bseg.ensure((size_t)nseq * nsegp * K * rs)) != PHK_OK) return rc;
+    if ((rc = h->bpi.ensure((size_t)nseq * K * sizeof(double))) != PHK_OK) return rc;
+    return PHK_OK;
+}
+
+// Enqueue one evaluation of `a` (ll, grad and scratch pointers set by the caller) under `plan`.
+// e_mid, if given, is recorded after the forward kernel.
+int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, bool want_grad, hipStream_t st,
+            hipEvent_t e_mid) {
+    const int K = h->K;
+    const int nt = 256;
+    const int64_t nseq = a.B * a.S;
+    hipError_t e;
+    a.seg_blocks = SEG_BLOCKS;
+    if (!want_grad) {
+        e = l.fwd(plan.R, plan.T, h->nrm, false, a, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
+        if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
+        return PHK_OK;
+    }
+    if (!h->dbl || plan.segmented) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
+    if (!plan.segmented) {
+        e = l.fwd(plan.R, plan.T, h->nrm, true, a, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
+        if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
+        e = l.bwd(plan.R, plan.T, h->nrm, a, 0, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "backward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
+        return PHK_OK;
+    }
+    // segmented: the beta scan needs nothing from the forward kernel -> second stream
+    const int64_t seg_sites = (int64_t)SEG_BLOCKS * plan.T;
+    HIP_TRY(hipEventRecord(h->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
+    if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_join, h->side));
+    e = l.fwd(plan.R1, plan.T, h->nrm, true, a, nt, st);
+    if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R1, plan.T, hipGetErrorString(e));
+    if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    const int units = (int)n_units(h, plan.T, a.W);
+    e = l.bwd(plan.R, plan.T, h->nrm, a, units, nt, st);
+    if (e != hipSuccess) return fail(PHK_EHIP, "segment kernel launch (K=%d R=%d T=%d units=%d): %s", K, plan.R, plan.T, units, hipGetErrorString(e));
+    e = l.fin(a, st);
+    if (e != hipSuccess) return fail(PHK_EHIP, "finalize kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+// Time candidate plans on this very batch (scratch outputs) and remember the fastest for this
+// (sequence count, gradient?) shape.  Serial candidates and the two latency-bound kernels of the
+// segmented plan are timed on the first TUNE_SITES sites (their cost is linear in L); the segmented
+// plan as a whole is timed once at full length because its parallelism depends on L.
+int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool want_grad, hipStream_t st) {
     const int K = h->K;
     const size_t rs = real_size(h);
     const int64_t nseq = proto.B * proto.S;
-    const int64_t tune_sites = std::min<int64_t>(h->L, 2048);
+    const int64_t tune_sites = std::min<int64_t>(h->L, TUNE_SITES);
     int rc;
     if ((rc = h->tune_ll.ensure((size_t)nseq * sizeof(double))) != PHK_OK) return rc;
     if (want_grad && (rc = h->tune_grad.ensure((size_t)nseq * 7 * K * rs)) != PHK_OK) return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    float best = 0.f;
-    int bestR = 0, bestT = 0;
+    phk::KArgs a = proto;
+    a.ll = (double*)h->tune_ll.p;
+    a.grad = want_grad ? h->tune_grad.p : nullptr;
+    auto timed = [&](const phk::KArgs& ka, const Plan& p, bool grad, float* ms) -> int {
+        for (int rep = 0; rep < 2; ++rep) {  // rep 0 loads the code objects / warms the caches
+            HIP_TRY(hipEventRecord(e0, st));
+            int r = enqueue(h, l, ka, p, grad, st, nullptr);
+            if (r != PHK_OK) return r;
+            HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+        }
+        return PHK_OK;
+    };
+    phk::KArgs at = a;  // truncated problem
+    at.Ltot = tune_sites;
+    at.W = std::min<int64_t>(proto.W, tune_sites);
+    Plan best;
+    float best_ms = 0.f;
     for (int R = 1; R <= 16; R <<= 1) {
         if (!valid_R(K, R)) continue;
         for (int T = 8; T <= 16; T += 8) {
             if (!valid_T(K, R, T)) continue;
-            phk::KArgs a = proto;
-            a.Ltot = tune_sites;
-            a.W = std::min<int64_t>(proto.W, tune_sites);
-            a.ll = (double*)h->tune_ll.p;
-            a.grad = want_grad ? h->tune_grad.p : nullptr;
+            Plan p;
+            p.R = R;
+            p.T = T;
             float ms = 0.f;
-            for (int rep = 0; rep < 2; ++rep) {  // rep 0 loads the code object / warms the caches
-                if (want_grad && !h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
+            if ((rc = timed(at, p, want_grad, &ms)) != PHK_OK) return rc;
+            if (best_ms == 0.f || ms < best_ms) {
+                best_ms = ms;
+                best = p;
+            }
+        }
+    }
+    // segmented plan: only worth a look where the serial sweep cannot fill the chip
+    const int64_t units = n_units(h, 8, proto.W);
+    if (want_grad && h->L >= 4 * TUNE_SITES && units >= 8 && nseq * best.R / 64 < 1024) {
+        Plan sp;
+        sp.segmented = 1;
+        sp.T = 8;
+        sp.R = throughput_R(h, nseq * units, 8, 2);
+        // latency-bound pair: fastest forward-with-checkpoints R1 and fastest beta-scan R2
+        float b1 = 0.f, b2 = 0.f;
+        for (int R = 1; R <= 16; R <<= 1) {
+            if (!valid_R(K, R)) continue;
+            float ms = 0.f;
+            for (int rep = 0; rep < 2; ++rep) {
                 HIP_TRY(hipEventRecord(e0, st));
-                hipError_t e = lf(R, T, h->nrm, want_grad, a, 256, st);
-                if (e == hipSuccess && want_grad) e = lb(R, T, h->nrm, a, 256, st);
-                if (e != hipSuccess) return fail(PHK_EHIP, "autotune launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
+                phk::KArgs k1 = at;
+                k1.seg_blocks = SEG_BLOCKS;
+                hipError_t e = l.fwd(R, 8, h->nrm, true, k1, 256, st);
+                if (e != hipSuccess) return fail(PHK_EHIP, "autotune forward launch: %s", hipGetErrorString(e));
                 HIP_TRY(hipEventRecord(e1, st));
                 HIP_TRY(hipEventSynchronize(e1));
                 HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
             }
-            if (!bestR || ms < best) {
-                best = ms;
-                bestR = R;
-                bestT = T;
+            if (b1 == 0.f || ms < b1) { b1 = ms; sp.R1 = R; }
+            for (int rep = 0; rep < 2; ++rep) {
+                HIP_TRY(hipEventRecord(e0, st));
+                hipError_t e = l.bscan(R, h->nrm, at, (int64_t)SEG_BLOCKS * 8, h->bseg.p, (int32_t*)h->fseg.p, 256, st);
+                if (e != hipSuccess) return fail(PHK_EHIP, "autotune beta-scan launch: %s", hipGetErrorString(e));
+                HIP_TRY(hipEventRecord(e1, st));
+                HIP_TRY(hipEventSynchronize(e1));
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
             }
+            if (b2 == 0.f || ms < b2) { b2 = ms; sp.R2 = R; }
         }
+        float seg_ms = 0.f;
+        if ((rc = timed(a, sp, true, &seg_ms)) != PHK_OK) return rc;
+        const float serial_full = best_ms * (float)h->L / (float)tune_sites;
+        if (seg_ms < serial_full) best = sp;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (bestR) h->tuned[{nseq, want_grad ? 1 : 0}] = {bestR, bestT};
+    h->tuned[{nseq, want_grad ? 1 : 0}] = best;
     return PHK_OK;
 }
 
@@ -252,6 +417,12 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) h->ws_limit = (int64_t)(free_b / 2);
     else h->ws_limit = (int64_t)32 << 30;
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete h;
+        return fail(PHK_EHIP, "could not create the side stream");
+    }
 
     int rc = PHK_OK;
     int8_t* staged = nullptr;
@@ -289,12 +460,13 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
 int phk_destroy(phk_handle* h) {
     if (!h) return PHK_OK;
     (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    h->ckpt.release();
-    h->aux.release();
-    h->gacc.release();
-    h->tune_ll.release();
-    h->tune_grad.release();
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->tune_ll, &h->tune_grad})
+        b->release();
     if (h->packed) (void)hipFree(h->packed);
     delete h;
     return PHK_OK;
@@ -307,6 +479,13 @@ int phk_set_variant(phk_handle* h, int R, int T) {
     if (R != 0 && !valid_T(h->K, R, T ? T : 8)) return fail(PHK_EINVAL, "R=%d T=%d not available (T=16 needs K/R <= 4)", R, T);
     h->force_R = R;
     h->force_T = T;
+    return PHK_OK;
+}
+
+int phk_set_backward_mode(phk_handle* h, int mode) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (mode < -1 || mode > 1) return fail(PHK_EINVAL, "mode must be -1 (auto), 0 (serial) or 1 (segmented)");
+    h->mode = mode;
     return PHK_OK;
 }
 
@@ -327,12 +506,40 @@ int phk_set_rescale_interval(phk_handle* h, int nrm) {
 
 int phk_get_variant(phk_handle* h, int64_t B, int64_t S, int* R, int* T) {
     if (!h || !R || !T) return fail(PHK_EINVAL, "NULL argument");
-    if (B * S == h->last_total && h->last_R) {  // what the last call of this shape actually ran (slabs included)
-        *R = h->last_R;
-        *T = h->last_T;
+    Plan p = (B * S == h->last_total) ? h->last_plan : choose_plan(h, B * S, 0, 1);
+    *R = p.R;
+    *T = p.T;
+    return PHK_OK;
+}
+
+int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int R_scan) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (segmented < 0) {  // back to automatic
+        h->has_forced_plan = 0;
         return PHK_OK;
     }
-    choose_variant(h, B * S, R, T);
+    Plan p;
+    p.segmented = segmented ? 1 : 0;
+    p.R = R;
+    p.T = p.segmented ? 8 : T;
+    p.R1 = R_forward;
+    p.R2 = R_scan;
+    if (!valid_R(h->K, p.R) || !valid_T(h->K, p.R, p.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
+    if (p.segmented && (!valid_R(h->K, p.R1) || !valid_R(h->K, p.R2)))
+        return fail(PHK_EINVAL, "segmented plan needs valid R_forward and R_scan (got %d, %d)", R_forward, R_scan);
+    h->forced_plan = p;
+    h->has_forced_plan = 1;
+    return PHK_OK;
+}
+
+int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, int* R_scan) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    const Plan& p = h->last_plan;
+    if (segmented) *segmented = p.segmented;
+    if (R) *R = p.R;
+    if (T) *T = p.T;
+    if (R_forward) *R_forward = p.segmented ? p.R1 : p.R;
+    if (R_scan) *R_scan = p.segmented ? p.R2 : 0;
     return PHK_OK;
 }
 
@@ -342,7 +549,9 @@ int phk_set_workspace_limit(phk_handle* h, int64_t bytes) {
     return PHK_OK;
 }
 
-int64_t phk_workspace_bytes(phk_handle* h) { return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap) : 0; }
+int64_t phk_workspace_bytes(phk_handle* h) {
+    return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap) : 0;
+}
 
 int phk_set_profiling(phk_handle* h, int on) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
@@ -420,9 +629,8 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     if (B < 0 || S < 0) return fail(PHK_EINVAL, "B and S must be >= 0");
     if (W < 0 || W > h->L) return fail(PHK_EINVAL, "W=%lld outside [0, L=%lld]", (long long)W, (long long)h->L);
     if (B == 0 || S == 0) return PHK_OK;
-    fwd_fn lf = nullptr;
-    bwd_fn lb = nullptr;
-    if (!pick_launchers(h, &lf, &lb)) return fail(PHK_EUNSUPPORTED, "K=%d not compiled in", h->K);
+    Launchers l;
+    if (!pick_launchers(h, &l)) return fail(PHK_EUNSUPPORTED, "K=%d not compiled in", h->K);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t rs = real_size(h);
@@ -430,8 +638,6 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     const bool want_grad = grad != nullptr;
     h->n_last = 0;
     if (h->n_launches > 4096) h->n_launches = 0;  // nobody is collecting: recycle the event pool
-
-    const int nt_b = 256, nt_f = 256;
 
     // slab the (particle, chunk) grid so that the checkpoint store (sized for T = 8, the densest
     // spacing) stays under the workspace limit
@@ -447,70 +653,56 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
                 Ss = max_seq;
             }
         }
-        const int64_t slab = Bs * Ss;
-        int rc;
-        if ((rc = h->ckpt.ensure((size_t)slab * per_seq)) != PHK_OK) return rc;
-        if ((rc = h->aux.ensure((size_t)slab * sizeof(phk::SeqAux))) != PHK_OK) return rc;
-        if (!h->dbl && (rc = h->gacc.ensure((size_t)slab * 6 * K * sizeof(double))) != PHK_OK) return rc;
+        int rc = ensure_scratch(h, Bs * Ss);
+        if (rc != PHK_OK) return rc;
     }
 
-    // kernel variant for this launch shape: forced, tuned earlier, tuned now, or the static rule
-    const int64_t nseq_launch = std::min(Bs, B) * std::min(Ss, S);
-    if (h->autotune && !h->force_R && !h->force_T && h->L >= 512 && nseq_launch >= 64 &&
-        !h->tuned.count({nseq_launch, want_grad ? 1 : 0})) {
+    auto make_args = [&](int64_t b0, int64_t nb, int64_t s0, int64_t ns) {
         phk::KArgs a;
         a.packed = h->packed;
         a.Lw = h->Lw;
         a.Ltot = h->L;
         a.W = W;
-        a.inds = inds;
-        a.params = params;
+        a.inds = inds + s0;
+        a.params = (const char*)params + (size_t)(b0 * pstride_b + s0 * pstride_s) * rs;
         a.pstride_b = pstride_b;
         a.pstride_s = pstride_s;
-        a.B = std::min(Bs, B);
-        a.S = std::min(Ss, S);
-        a.ll = nullptr;
+        a.B = nb;
+        a.S = ns;
+        // with Ss < S the slab is one particle (nb == 1): rows b0*S + s0 .. are contiguous
+        a.ll = ll + b0 * S + s0;
         a.ckpt = want_grad ? h->ckpt.p : nullptr;
         a.aux = (phk::SeqAux*)h->aux.p;
-        a.grad = nullptr;
+        a.grad = want_grad ? (char*)grad + (size_t)(b0 * S + s0) * 7 * K * rs : nullptr;
         a.gacc = (double*)h->gacc.p;
         a.grad_dlog = grad_dlog;
-        int rc = autotune_variant(h, a, want_grad, lf, lb, st);
+        a.eblk = (int16_t*)h->eblk.p;
+        a.eseg = (int32_t*)h->eseg.p;
+        a.seg_blocks = SEG_BLOCKS;
+        a.bseg = h->bseg.p;
+        a.fseg = (const int32_t*)h->fseg.p;
+        a.bpi = (double*)h->bpi.p;
+        return a;
+    };
+
+    // plan for this launch shape: forced, tuned earlier, tuned now, or the static rule
+    const int64_t nseq_launch = std::min(Bs, B) * std::min(Ss, S);
+    if (h->autotune && !h->has_forced_plan && !h->force_R && !h->force_T && h->mode < 0 && h->L >= 512 && nseq_launch >= 64 &&
+        !h->tuned.count({nseq_launch, want_grad ? 1 : 0})) {
+        int rc = autotune(h, l, make_args(0, std::min(Bs, B), 0, std::min(Ss, S)), want_grad, st);
         if (rc != PHK_OK) return rc;
     }
-    int R = 1, T = 8;
-    choose_variant(h, nseq_launch, &R, &T, want_grad ? 1 : 0);
-    if (!valid_R(K, R)) return fail(PHK_EINVAL, "no valid lanes-per-sequence for K=%d", K);
-    if (!valid_T(K, R, T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, T, K);
+    const Plan plan = choose_plan(h, nseq_launch, W, want_grad ? 1 : 0);
+    if (!valid_R(K, plan.R) || !valid_T(K, plan.R, plan.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
+    if (plan.segmented && (!valid_R(K, plan.R1) || !valid_R(K, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
     h->last_total = B * S;
-    h->last_R = R;
-    h->last_T = T;
+    h->last_plan = plan;
 
     for (int64_t b0 = 0; b0 < B; b0 += Bs) {
         const int64_t nb = std::min(Bs, B - b0);
         for (int64_t s0 = 0; s0 < S; s0 += Ss) {
             const int64_t ns = std::min(Ss, S - s0);
-            phk::KArgs a;
-            a.packed = h->packed;
-            a.Lw = h->Lw;
-            a.Ltot = h->L;
-            a.W = W;
-            a.inds = inds + s0;
-            a.params = (const char*)params + (size_t)(b0 * pstride_b + s0 * pstride_s) * rs;
-            a.pstride_b = pstride_b;
-            a.pstride_s = pstride_s;
-            a.B = nb;
-            a.S = ns;
-            // with Ss < S the slab is one particle (nb == 1): rows b0*S + s0 .. are contiguous
-            a.ll = ll + b0 * S + s0;
-            a.ckpt = want_grad ? h->ckpt.p : nullptr;
-            a.aux = (phk::SeqAux*)h->aux.p;
-            a.grad = want_grad ? (char*)grad + (size_t)(b0 * S + s0) * 7 * K * rs : nullptr;
-            a.gacc = (double*)h->gacc.p;
-            a.grad_dlog = grad_dlog;
-
-            if (want_grad && !h->dbl)
-                HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nb * ns * 6 * K * sizeof(double), st));
+            const phk::KArgs a = make_args(b0, nb, s0, ns);
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             if (h->profiling) {
                 while ((int)h->ev.size() < 3 * (h->n_launches + 1)) {
@@ -523,13 +715,8 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
                 e2 = h->ev[3 * h->n_launches + 2];
                 HIP_TRY(hipEventRecord(e0, st));
             }
-            hipError_t e = lf(R, T, h->nrm, want_grad, a, nt_f, st);
-            if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
-            if (h->profiling) HIP_TRY(hipEventRecord(e1, st));
-            if (want_grad) {
-                e = lb(R, T, h->nrm, a, nt_b, st);
-                if (e != hipSuccess) return fail(PHK_EHIP, "backward kernel launch (K=%d R=%d T=%d): %s", K, R, T, hipGetErrorString(e));
-            }
+            int rc = enqueue(h, l, a, plan, want_grad, st, e1);
+            if (rc != PHK_OK) return rc;
             if (h->profiling) {
                 HIP_TRY(hipEventRecord(e2, st));
                 h->n_launches++;

@@ -335,6 +335,50 @@ struct Lane {
             beta[h] = fma2<real>(u[h], svw[h], nb);
         }
     }
+
+    // One step of the unnormalised backward recursion b*_{t-1} = A (e_t .* b*_t), then (SCALE) a
+    // power-of-two rescale of its own; returns the exponent removed.  Used by the beta scan only.
+    __device__ __forceinline__ int bt_site(V (&beta)[NP], const V (&e)[NP], const bool SCALE) const {
+        V w[NP], svw[NP], pbw[NP];
+#pragma unroll
+        for (int h = 0; h < NP; ++h) w[h] = beta[h] * e[h];
+        real tv = real(0);
+#pragma unroll
+        for (int i = 2 * NP - 1; i >= 0; --i) {
+            svw[i >> 1][i & 1] = tv;
+            if (i < SPL) tv = fma_(get(v, i), get(w, i), tv);
+        }
+        real tb = real(0);
+#pragma unroll
+        for (int i = 0; i < 2 * NP; ++i) {
+            pbw[i >> 1][i & 1] = tb;
+            if (i < SPL) tb = fma_(get(b, i), get(w, i), tb);
+        }
+        if constexpr (R > 1) {
+            const V cv = splat<real>(g.excl_suffix(tv));
+            const V cb = splat<real>(g.excl_prefix(tb));
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                svw[h] = svw[h] + cv;
+                pbw[h] = pbw[h] + cb;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            V nb = d[h] * w[h];
+            nb = nb + pbw[h];
+            beta[h] = fma2<real>(u[h], svw[h], nb);
+        }
+        if (SCALE) {
+            const real c = total(beta);
+            const int ex = frexp_exp_(c);
+            const V s2 = splat<real>(ldexp_(real(1), -ex));
+#pragma unroll
+            for (int h = 0; h < NP; ++h) beta[h] = beta[h] * s2;
+            return ex;
+        }
+        return 0;
+    }
 };
 
 // 2-bit observation codes: 16 sites per dword; site t of a row -> bits [2*(t%16), +2) of word t/16
@@ -345,6 +389,8 @@ __device__ __forceinline__ uint32_t block_codes(const uint32_t* __restrict__ wor
 struct SeqAux {      // written by the forward kernel, read by the backward kernel
     double inv_end;  // 1 / sum(alpha) after the last site (scaled state)
     double inv_w;    // 1 / sum(alpha) after the W-th site (0 if W == 0)
+    int32_t e_end;   // exponent total E after the last site: true alpha_L = alpha * 2^E
+    int32_t pad_;
 };
 
 struct KArgs {
@@ -363,6 +409,14 @@ struct KArgs {
     void* grad;              // [B*S, 7, K] real
     double* gacc;            // [B*S, 6, K] f64 partial sums (f32 kernels), zeroed before launch
     int grad_dlog;           // 1: return theta * d ll/d theta (what the reference kernel returns)
+    // scale bookkeeping written by the forward kernel (lets the backward kernel use another variant)
+    int16_t* eblk;           // [nblk, B*S] exponent total of every block
+    int32_t* eseg;           // [nseg+1, B*S] exponent total before the first site of every segment
+    // segmented (small-batch) backward: independent units of seg_blocks blocks per sequence
+    int seg_blocks;          // blocks per segment (0: one serial sweep per sequence)
+    const void* bseg;        // [nseg+1, B*S, K] real: scaled b*_t = A(e.b*) recursion at segment starts
+    const int32_t* fseg;     // [nseg+1, B*S] its exponents
+    double* bpi;             // [B*S, K] d ll / d pi (segmented mode; the serial kernel writes grad itself)
 };
 
 constexpr double LN2 = 0.693147180559945309417232121458;
@@ -421,6 +475,10 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                 for (int i = 0; i < SPL; ++i) dst[i] = L::get(a, i);
             }
         }
+        const int E0 = E;
+        if constexpr (CKPT) {
+            if (active && rank == 0 && A.seg_blocks > 0 && blk % A.seg_blocks == 0) A.eseg[(blk / A.seg_blocks) * nseq + seq] = E;
+        }
         const uint32_t codes = block_codes(words, t0);
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
         if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
@@ -456,6 +514,9 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                 }
             }
         }
+        if constexpr (CKPT) {
+            if (active && rank == 0) A.eblk[blk * nseq + seq] = (int16_t)(E - E0);
+        }
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (active && rank == 0) {
@@ -463,6 +524,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         if constexpr (CKPT) {
             A.aux[seq].inv_end = 1.0 / cend;
             A.aux[seq].inv_w = invW;
+            A.aux[seq].e_end = E;
         }
     }
 }
@@ -476,7 +538,12 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
 template <typename real, int K, int R, int T>
 constexpr int bwd_waves_per_simd() { return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1; }
 
-template <typename real, int K, int R, int T, int NRM>
+// SEG = false: one unit per sequence sweeps all blocks (blockIdx.y == 0) and writes the gradient.
+// SEG = true : blockIdx.y picks a unit of A.seg_blocks blocks; it starts from the beta-scan's value
+//   at its right edge, adds its partial sums into gacc with f64 atomics, and grad_finalize_kernel
+//   writes the gradient.  Unit 0 also covers every segment up to the one holding the warm-up
+//   boundary (the correction there makes those segments depend on each other).
+template <typename real, int K, int R, int T, int NRM, bool SEG>
 __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void bwd_kernel(KArgs A) {
     using L = Lane<real, K, R>;
     using V = typename L::V;
@@ -502,23 +569,44 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     V beta[NP], gb[NP], gd[NP], gu[NP], gv[NP], g0[NP], g1[NP];
     const real inv_end = (real)A.aux[seq].inv_end;
     const real inv_w = (real)A.aux[seq].inv_w;
+    const int64_t nblk = (A.Ltot + T - 1) / T;
+    // block range [blk_lo, blk_hi) of this unit
+    int64_t blk_lo = 0, blk_hi = nblk;
+    if constexpr (SEG) {
+        const int64_t G = A.seg_blocks;
+        const int64_t segW = A.W > 0 ? ((A.W - 1) / T) / G : 0;  // segment holding the warm-up boundary
+        const int64_t seg = segW + blockIdx.y;
+        blk_lo = blockIdx.y == 0 ? 0 : seg * G;
+        blk_hi = (seg + 1) * G < nblk ? (seg + 1) * G : nblk;
+    }
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
         beta[h] = splat<real>(inv_end);
         gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
     }
-    constexpr bool F64ACC = sizeof(real) == 4;  // f32 kernels fold partial sums into f64
+    if constexpr (SEG) {
+        if (blk_hi < nblk) {
+            // adjoint of the scaled alpha at the unit's right edge t: b*_t 2^{E_t} / P,
+            // b*_t = bseg 2^{fseg},  P = sum(alpha_L) 2^{E_L}
+            const int64_t sb = blk_hi / A.seg_blocks;
+            const real* src = (const real*)A.bseg + (sb * nseq + seq) * K + rank * SPL;
+            const int ex = A.fseg[sb * nseq + seq] + A.eseg[sb * nseq + seq] - A.aux[seq].e_end;
+            const real f = ldexp_(inv_end, ex);
+#pragma unroll
+            for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? src[i < SPL ? i : 0] * f : real(0);
+        }
+    }
+    constexpr bool F64ACC = sizeof(real) == 4 || SEG;  // fold partial sums into the f64 buffer
     double* gacc = A.gacc + seq * 6 * K + rank * SPL;
     int since_flush = 0;
 
-    const int64_t nblk = (A.Ltot + T - 1) / T;
     real anext[SPL];
-    if (nblk > 0) {
-        const real* src = ck + ((nblk - 1) * nseq + seq) * K + rank * SPL;
+    if (blk_hi > blk_lo) {
+        const real* src = ck + ((blk_hi - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) anext[i] = src[i];
     }
-    for (int64_t blk = nblk - 1; blk >= 0; --blk) {
+    for (int64_t blk = blk_hi - 1; blk >= blk_lo; --blk) {
         const int64_t t0 = blk * T;
         V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
         real sc[T / NRM];
@@ -527,7 +615,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
             al[0][h][0] = anext[2 * h];
             al[0][h][1] = (2 * h + 1 < SPL) ? anext[(2 * h + 1 < SPL) ? 2 * h + 1 : 0] : real(0);
         }
-        if (blk > 0) {  // prefetch the previous block's checkpoint under this block's arithmetic
+        const int e_fwd = A.eblk[blk * nseq + seq];  // exponent total the forward kernel took out of this block
+        int e_run = 0;                               // ... and the re-run below
+        if (blk > blk_lo) {  // prefetch the previous block's checkpoint under this block's arithmetic
             const real* src = ck + ((blk - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
             for (int i = 0; i < SPL; ++i) anext[i] = src[i];
@@ -549,13 +639,19 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
 #pragma unroll
                 for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
                 real s;
-                lane.fwd_site(al[i + 1], ec, s, rescale_after<NRM>(i));
+                e_run += lane.fwd_site(al[i + 1], ec, s, rescale_after<NRM>(i));
                 if (rescale_after<NRM>(i)) sc[i / NRM] = s;
                 if (i + 1 < T) {  // (the last forward step and the first backward step share a row)
 #pragma unroll
                     for (int h = 0; h < NP; ++h) ec[h] = en[h];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // beta is the adjoint of the forward kernel's alpha at the block end; the re-run's
+                // alpha is that times 2^(e_fwd - e_run) (0 when both kernels are the same variant)
+                const V fx = splat<real>(ldexp_(real(1), e_run - e_fwd));
+#pragma unroll
+                for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
             }
             // sweep it backwards
 #pragma unroll
@@ -580,9 +676,14 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
                     real s;
                     V e[NP];
                     lane.emis((codes >> (2 * i)) & 3, e);
-                    lane.fwd_site(al[i + 1], e, s, rescale_after<NRM>(i));
+                    e_run += lane.fwd_site(al[i + 1], e, s, rescale_after<NRM>(i));
                     if (rescale_after<NRM>(i)) sc[i / NRM] = s;
                 }
+            }
+            {
+                const V fx = splat<real>(ldexp_(real(1), e_run - e_fwd));
+#pragma unroll
+                for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
             }
 #pragma unroll
             for (int i = T - 1; i >= 0; --i) {
@@ -601,17 +702,26 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         }
         if constexpr (F64ACC) {
             since_flush += ns;
-            if (since_flush >= FLUSH_SITES || blk == 0) {
+            if (since_flush >= FLUSH_SITES || blk == blk_lo) {
                 since_flush = 0;
                 if (active) {
 #pragma unroll
                     for (int i = 0; i < SPL; ++i) {
-                        gacc[0 * K + i] += (double)L::get(gb, i);
-                        gacc[1 * K + i] += (double)L::get(gd, i);
-                        gacc[2 * K + i] += (double)L::get(gu, i);
-                        gacc[3 * K + i] += (double)L::get(gv, i);
-                        gacc[4 * K + i] += (double)L::get(g0, i);
-                        gacc[5 * K + i] += (double)L::get(g1, i);
+                        if constexpr (SEG) {  // several units add into one sequence's sums
+                            unsafeAtomicAdd(&gacc[0 * K + i], (double)L::get(gb, i));
+                            unsafeAtomicAdd(&gacc[1 * K + i], (double)L::get(gd, i));
+                            unsafeAtomicAdd(&gacc[2 * K + i], (double)L::get(gu, i));
+                            unsafeAtomicAdd(&gacc[3 * K + i], (double)L::get(gv, i));
+                            unsafeAtomicAdd(&gacc[4 * K + i], (double)L::get(g0, i));
+                            unsafeAtomicAdd(&gacc[5 * K + i], (double)L::get(g1, i));
+                        } else {
+                            gacc[0 * K + i] += (double)L::get(gb, i);
+                            gacc[1 * K + i] += (double)L::get(gd, i);
+                            gacc[2 * K + i] += (double)L::get(gu, i);
+                            gacc[3 * K + i] += (double)L::get(gv, i);
+                            gacc[4 * K + i] += (double)L::get(g0, i);
+                            gacc[5 * K + i] += (double)L::get(g1, i);
+                        }
                     }
                 }
 #pragma unroll
@@ -620,6 +730,13 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         }
     }
     if (!active) return;
+    if constexpr (SEG) {
+        if (blk_lo == 0) {
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) A.bpi[seq * K + rank * SPL + i] = (double)L::get(beta, i);
+        }
+        return;  // grad_finalize_kernel turns gacc / bpi into the gradient
+    }
     // d ll / d theta (or theta * that), rows b,d,u,v,emis0,emis1,pi
     real* out = (real*)A.grad + seq * 7 * K + rank * SPL;
     const bool dl = A.grad_dlog != 0;
@@ -641,6 +758,94 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + i]);
         out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)L::get(pi, i) : (double)L::get(beta, i));
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 3 (small batches): the unnormalised backward recursion alone, b*_L = 1,
+// b*_{t-1} = A (e_t .* b*_t), with its own power-of-two scaling; the state at every segment start is
+// kept.  It does not depend on the forward kernel, so the two run concurrently on two streams, and
+// the segments of a sequence can then be swept in parallel by bwd_kernel<..., SEG = true>.
+// ---------------------------------------------------------------------------------------------
+template <typename real, int K, int R, int NRM>
+__global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_sites, void* bseg_out, int32_t* fseg_out) {
+    using L = Lane<real, K, R>;
+    using V = typename L::V;
+    constexpr int SPL = L::SPL, NP = L::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int64_t nseq = A.B * A.S;
+    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
+    const bool active = gid < nseq;
+    const int64_t seq = active ? gid : nseq - 1;
+    const int rank = threadIdx.x & (R - 1);
+    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+
+    L lane;
+    V pi[NP], beta[NP];
+    lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
+              (real*)smem_raw + (size_t)threadIdx.x * (3 * L::EROW), pi);
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? real(1) : real(0);
+    const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
+    int F = 0;
+    const int64_t nw = (A.Ltot + 15) / 16;
+    for (int64_t w = nw - 1; w >= 0; --w) {
+        const int64_t t_hi = (w + 1) * 16;  // first site to the right of this word
+        if (t_hi < A.Ltot && t_hi % seg_sites == 0) {
+            const int64_t sb = t_hi / seg_sites;
+            if (active) {
+                real* dst = (real*)bseg_out + (sb * nseq + seq) * K + rank * SPL;
+#pragma unroll
+                for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
+                if (rank == 0) fseg_out[sb * nseq + seq] = F;
+            }
+        }
+        const uint32_t codes = words[w];
+        const int ns = (int)((A.Ltot - w * 16) < 16 ? (A.Ltot - w * 16) : 16);
+        if (ns == 16) {
+            V ec[NP];
+            lane.emis(codes >> 30, ec);
+#pragma unroll
+            for (int j = 15; j >= 0; --j) {
+                V en[NP];
+                if (j > 0) lane.emis((codes >> (2 * (j - 1))) & 3, en);
+                F += lane.bt_site(beta, ec, rescale_after<NRM>(j));
+                if (j > 0) {
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 15; j >= 0; --j) {
+                if (j < ns) {
+                    V e[NP];
+                    lane.emis((codes >> (2 * j)) & 3, e);
+                    F += lane.bt_site(beta, e, rescale_after<NRM>(j));
+                }
+            }
+        }
+    }
+}
+
+// gacc [B*S, 6, K] + bpi [B*S, K] -> grad [B*S, 7, K]   (segmented mode)
+template <typename real>
+__global__ void grad_finalize_kernel(KArgs A, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nseq = A.B * A.S;
+    if (idx >= nseq * K) return;
+    const int64_t seq = idx / K;
+    const int k = (int)(idx - seq * K);
+    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+    const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
+    const double* ga = A.gacc + seq * 6 * K;
+    real* out = (real*)A.grad + seq * 7 * K;
+    const bool dl = A.grad_dlog != 0;
+    for (int r = 0; r < 4; ++r) out[r * K + k] = (real)(dl ? ga[r * K + k] * (double)p[r * K + k] : ga[r * K + k]);
+    out[4 * K + k] = (real)(dl ? ga[4 * K + k] : ga[4 * K + k] / (double)p[4 * K + k]);
+    out[5 * K + k] = (real)(dl ? ga[5 * K + k] : ga[5 * K + k] / (double)p[5 * K + k]);
+    const double bp = A.bpi[seq * K + k];
+    out[6 * K + k] = (real)(dl ? bp * (double)p[6 * K + k] : bp);
 }
 
 // ---------------------------------------------------------------------------------------------

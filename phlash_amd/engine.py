@@ -64,6 +64,18 @@ class HipEngine:
     def set_autotune(self, on: bool):
         _lib.check(_lib.load().phk_set_autotune(self._h, int(bool(on))))
 
+    def set_backward_mode(self, mode: int = -1):
+        """-1 automatic, 0 serial sweep per sequence, 1 segmented (small batches)."""
+        _lib.check(_lib.load().phk_set_backward_mode(self._h, int(mode)))
+
+    def set_plan(self, segmented: int = -1, R: int = 0, T: int = 8, R_forward: int = 0, R_scan: int = 0):
+        _lib.check(_lib.load().phk_set_plan(self._h, int(segmented), int(R), int(T), int(R_forward), int(R_scan)))
+
+    def get_plan(self) -> dict:
+        v = [ctypes.c_int() for _ in range(5)]
+        _lib.check(_lib.load().phk_get_plan(self._h, *(ctypes.byref(x) for x in v)))
+        return dict(zip(("segmented", "R", "T", "R_forward", "R_scan"), (x.value for x in v)))
+
     def get_variant(self, B: int, S: int) -> tuple[int, int]:
         r, t = ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.load().phk_get_variant(self._h, int(B), int(S), ctypes.byref(r), ctypes.byref(t)))

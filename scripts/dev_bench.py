@@ -50,7 +50,7 @@ def main():
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             f, b, n = eng.last_timing()
-        print(f"auto -> R,T={eng.get_variant(a.B, a.S)} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall * 1e3:8.2f} ms launches={n} "
+        print(f"auto -> plan={eng.get_plan()} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall * 1e3:8.2f} ms launches={n} "
               f"-> {work / ((f + b) * 1e-3):.3e} site-particle/s", flush=True)
         return
     for v in a.variants.split(","):

@@ -209,3 +209,59 @@ def test_autotune_picks_a_valid_variant_and_keeps_results(rng):
     eng.set_autotune(False)
     ll2, g2 = _run(eng, P, inds, 100)  # static rule
     _check(ll2, g2, ll_ref, g_ref, False)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+@pytest.mark.parametrize("K", [16, 64])
+def test_segmented_backward(K, dbl, rng):
+    """Small-batch plan: forward kernel || beta scan on two streams, then every 512-site segment of
+    every sequence swept independently (different lanes-per-sequence in the three kernels, so the
+    exponent reconciliation between them is exercised), against the oracle."""
+    L = 3300  # 7 segments, the last one partial
+    data = (rng.uniform(size=(5, L)) < 0.06).astype(np.int8)
+    data.flat[rng.integers(0, data.size, 150)] = -1
+    data[:, 0] = 0
+    eng = _engine(K, data, dbl)
+    eng.set_autotune(False)
+    eng.set_plan(1, R=4 if K == 16 else 8, R_forward=16, R_scan=2 if K == 16 else 4)
+    P = _params(K, 3, 1, seed=5)
+    inds = np.array([4, 0, 2, 2])
+    for W in (0, 100, 512, 700, L):
+        ll, g = _run(eng, P, inds, W)
+        plan = eng.get_plan()
+        assert plan["segmented"] == 1
+        ll_ref, g_ref = cport.batch(P, data, inds, W)
+        _check(ll, g, ll_ref, g_ref, dbl)
+    assert plan["R_forward"] != plan["R"]  # the kernels really ran as different variants
+    # same lanes-per-sequence everywhere, every rescale interval, d/dlog output
+    eng.set_plan(-1)
+    eng.set_backward_mode(1)
+    for R, nrm in ((4, 1), (16, 2)) if K == 16 else ((8, 4),):
+        eng.set_variant(R, 8)
+        eng.set_rescale_interval(nrm)
+        ll, g = _run(eng, P, inds, 100, dlog=True)
+        ll_ref, g_ref = cport.batch(P, data, inds, 100)
+        _check(ll, g, ll_ref, g_ref * P, dbl)
+    # serial and segmented plans agree
+    eng.set_variant(0, 0)
+    eng.set_rescale_interval(0)
+    ll_seg, g_seg = _run(eng, P, inds, 100)
+    eng.set_backward_mode(0)
+    ll_ser, g_ser = _run(eng, P, inds, 100)
+    assert eng.get_plan()["segmented"] == 0
+    np.testing.assert_allclose(ll_seg, ll_ser, rtol=1e-12 if dbl else 1e-6)
+    scale = np.maximum(np.abs(g_ser).max(-1, keepdims=True), 1.0)
+    assert (np.abs(g_seg - g_ser) / scale).max() < (1e-9 if dbl else 2e-3)
+
+
+def test_segmented_short_rows_fall_back_to_one_unit(rng):
+    data = (rng.uniform(size=(3, 200)) < 0.1).astype(np.int8)
+    data[:, 0] = 0
+    eng = _engine(16, data, True)
+    eng.set_autotune(False)
+    eng.set_backward_mode(1)
+    P = _params(16, 2, 1, seed=6)
+    for W in (0, 50):
+        ll, g = _run(eng, P, np.arange(3), W)
+        ll_ref, g_ref = cport.batch(P, data, np.arange(3), W)
+        _check(ll, g, ll_ref, g_ref, True)
