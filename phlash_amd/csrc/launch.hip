@@ -17,7 +17,12 @@ constexpr int KK = PHK_K;
 
 static size_t lds_bytes(int R, int nt) {
     const int spl = KK / R;
-    return (size_t)3 * (2 * ((spl + 1) / 2)) * nt * sizeof(real_t);  // per-thread emission table
+    const int erow = 2 * ((spl + 1) / 2);
+    const int w = (int)(sizeof(real_t) / 4);
+    int raw = 3 * erow;  // per-thread emission table, padded as Lane::ETAB_STRIDE
+    const int dw = raw * w;
+    if (dw % 4 == 0 && (dw / 4) % 2 == 0) raw += 4 / w;
+    return (size_t)raw * nt * sizeof(real_t);
 }
 
 template <int R, int T, int NRM>

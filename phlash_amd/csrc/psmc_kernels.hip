@@ -182,6 +182,13 @@ struct Lane {
     static constexpr int SPL = K / R;        // states owned by this lane
     static constexpr int NP = (SPL + 1) / 2;  // packed pairs (odd SPL: the last pair's .y is padding)
     static constexpr int EROW = 2 * NP;       // reals per emission row in the LDS table
+    // reals per thread in the LDS table: 3 rows, padded so that the per-thread stride in 16-byte
+    // units is odd -- then the 16 lanes of a ds_read_b128 group fall on 16 different bank quads
+    // (with an even stride, lanes l and l+8 collide: SQ_LDS_BANK_CONFLICT was 6-9 % of wave cycles)
+    static constexpr int ETAB_RAW = 3 * EROW;
+    static constexpr int ETAB_DW = ETAB_RAW * (int)(sizeof(real) / 4);
+    static constexpr int ETAB_STRIDE =
+        (ETAB_DW % 4 == 0 && (ETAB_DW / 4) % 2 == 0) ? ETAB_RAW + 4 / (int)(sizeof(real) / 4) : ETAB_RAW;
     static_assert(SPL * R == K, "R must divide K");
     using V = vec2<real>;
 
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     L lane;
     V a[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
-              (real*)smem_raw + (size_t)threadIdx.x * (3 * L::EROW), a);
+              (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
 
     int E = 0;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     L lane;
     V pi[NP];
     const real* prm = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
-    real* etab = (real*)smem_raw + (size_t)tid * (3 * L::EROW);
+    real* etab = (real*)smem_raw + (size_t)tid * L::ETAB_STRIDE;
     lane.load(prm, rank, etab, pi);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
     const real* ck = (const real*)A.ckpt;
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     L lane;
     V pi[NP], beta[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
-              (real*)smem_raw + (size_t)threadIdx.x * (3 * L::EROW), pi);
+              (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? real(1) : real(0);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;

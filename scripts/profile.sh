@@ -8,6 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export PHK_AUTOTUNE=0   # profile the static plan only (the tuner would add short runs of every variant)
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
