@@ -173,7 +173,8 @@ def main():
             except Exception:
                 traffic = None
         flops = 48.0 * K * B * S * L  # fwd 12K + re-run 12K + backward 24K per site.particle
-        R, T = kern._eng.get_variant(B, S)
+        plan = kern._eng.get_plan()
+        R, T = plan["R"], plan["T"]
         out = {
             "metric": "site·particle forward+grad evals/sec at K=16; log-lik rel-err vs JAX ref",
             "value": value,
@@ -192,7 +193,8 @@ def main():
                             f"K={K}, {B} SVGD particles; full inner step (param map, HIP fwd+bwd, "
                             f"all-reduce, chain rule, SVGD update)",
                 "K": K, "particles": B, "chunks_per_gpu": S, "chunk_size": L, "overlap": W,
-                "kernel_variant": {"lanes_per_sequence": R, "checkpoint_block": T},
+                "kernel_variant": {"lanes_per_sequence": R, "checkpoint_block": T,
+                                   "plan": "segmented" if plan["segmented"] else "serial"},
                 "sharding": f"chunk rows sharded over {world} rank(s), one all-reduce of [B, 1+7K] f64 per step",
             },
             "kernel_ms_per_step": {"forward": fwd_ms / a.steps, "backward": bwd_ms / a.steps},
