@@ -18,10 +18,13 @@ from .util import Pattern
 
 
 def simulate_chunks(K: int, n_rows: int, n_sites: int, seed: int, theta: float = 1e-2, rho: float = 1e-2,
-                    missing: float = 0.01) -> np.ndarray:
-    """int8 [n_rows, n_sites] in {-1, 0, 1}: all rows advance together, one vectorised draw per site."""
+                    missing: float = 0.01, c=None) -> np.ndarray:
+    """int8 [n_rows, n_sites] in {-1, 0, 1}: all rows advance together, one vectorised draw per site.
+    ``c`` (optional, [K]) replaces the default constant coalescence rate 1 on the default time grid."""
     rng = np.random.default_rng(seed)
     dm = DemographicModel.default(f"{K}*1", theta, rho)
+    if c is not None:
+        dm = DemographicModel(eta=type(dm.eta)(t=dm.eta.t, c=torch.as_tensor(np.asarray(c, dtype=np.float64))), theta=theta, rho=rho)
     A = transition_matrix(dm).numpy()
     A = np.clip(A, 0.0, None)
     cumA = np.cumsum(A / A.sum(1, keepdims=True), axis=1)

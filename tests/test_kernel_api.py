@@ -216,3 +216,26 @@ def test_param_map_kernel_vs_torch_definition(K, pattern, rng):
     assert float(((ga - gb).abs() / scale).max()) < 1e-8
     # no-grad call allocates no Jacobian and gives the same values
     np.testing.assert_array_equal(particles_to_params(init, x).cpu(), got.detach().cpu())
+
+
+def test_fit_recovers_a_known_size_history():
+    """Statistical validation of the sampler (its SVGD/AMSGrad arithmetic is parity-unpinned): data
+    simulated from the HMM with coalescence rate 0.5 everywhere (twice the default population size)
+    must pull the particles, started at rate 1, to rate ~0.5 in the well-informed middle epochs."""
+    import phlash_amd
+    from phlash_amd.data import RawContig
+    from phlash_amd.synth import simulate_chunks
+
+    K = 16
+    het = simulate_chunks(K, 24, 40_000, seed=11, theta=1e-2, rho=1e-2, missing=0.0, c=np.full(K, 0.5))
+    ctgs = [RawContig(h[None], np.array([1]), 100) for h in het]
+    res = phlash_amd.fit(ctgs, niter=300, num_particles=32, chunk_size=10_000, overlap=500, minibatch_size=16,
+                         theta=1e-2 / 100, progress=False, key=3, t1=1e-3, learning_rate=0.1)
+    c = np.stack([np.asarray(dm.eta.c) for dm in res])  # [particles, K]
+    t = np.asarray(res[0].eta.t)
+    mid = (t > 0.3) & (t < 3.0)  # epochs with plenty of coalescences (the most recent ones are barely informed)
+    assert mid.sum() >= 5
+    post = np.exp(np.log(c[:, mid]).mean())
+    assert 0.35 < post < 0.7, f"posterior geometric-mean rate in the middle epochs {post:.3f}, truth 0.5"
+    rot = np.mean([dm.rho / dm.theta for dm in res])
+    assert 0.5 < rot < 2.0, f"rho/theta {rot:.2f}, truth 1"
