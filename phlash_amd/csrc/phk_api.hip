@@ -92,14 +92,16 @@ struct DevBuf {
 };
 
 // How one launch shape is evaluated.
-//   serial   : forward kernel (R, T) -> backward kernel (R, T), one sweep per sequence.  Large batches.
+//   serial   : forward kernel (R1 or R, T) -> backward kernel (R, T), one sweep per sequence.  Large
+//              batches.  The two kernels may be different variants: the forward kernel records the
+//              exponent it took out of every block and the backward kernel reconciles its re-run.
 //   segmented: forward kernel (R1, T) on the call's stream || beta scan (R2) on a second stream ->
 //              backward kernel (R3, T) over independent segments -> finalize.  Small batches, where
 //              a serial sweep leaves most of the chip idle.
 struct Plan {
     int segmented = 0;
-    int R = 2, T = 8;    // serial: both kernels; segmented: R = R3 of the segment sweep
-    int R1 = 0, R2 = 0;  // segmented: forward kernel / beta scan
+    int R = 2, T = 8;    // serial: backward kernel; segmented: R = R3 of the segment sweep
+    int R1 = 0, R2 = 0;  // forward kernel (0: same as R) / beta scan (segmented only)
 };
 
 }  // namespace
@@ -245,15 +247,16 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     hipError_t e;
     a.seg_blocks = SEG_BLOCKS;
     if (!want_grad) {
-        e = l.fwd(plan.R, plan.T, h->nrm, false, a, nt, st);
+        e = l.fwd(plan.R1 && !plan.segmented ? plan.R1 : plan.R, plan.T, h->nrm, false, a, nt, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         return PHK_OK;
     }
     if (!h->dbl || plan.segmented) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
     if (!plan.segmented) {
-        e = l.fwd(plan.R, plan.T, h->nrm, true, a, nt, st);
-        if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
+        const int Rf = plan.R1 ? plan.R1 : plan.R;
+        e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, Rf, plan.T, hipGetErrorString(e));
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         e = l.bwd(plan.R, plan.T, h->nrm, a, 0, nt, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "backward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
@@ -312,19 +315,46 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     at.W = std::min<int64_t>(proto.W, tune_sites);
     Plan best;
     float best_ms = 0.f;
-    for (int R = 1; R <= 16; R <<= 1) {
-        if (!valid_R(K, R)) continue;
-        for (int T = 8; T <= 16; T += 8) {
-            if (!valid_T(K, R, T)) continue;
-            Plan p;
-            p.R = R;
-            p.T = T;
+    auto time_launch = [&](auto&& launch, float* ms) -> int {
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_TRY(hipEventRecord(e0, st));
+            hipError_t e = launch();
+            if (e != hipSuccess) return fail(PHK_EHIP, "autotune launch: %s", hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+        }
+        return PHK_OK;
+    };
+    at.seg_blocks = SEG_BLOCKS;
+    for (int T = 8; T <= 16; T += 8) {
+        // the forward and the backward kernel are timed separately (any forward variant leaves valid
+        // checkpoints for any backward variant of the same T) and the fastest of each is kept
+        int bf = 0, bb = 0;
+        float tf = 0.f, tb = 0.f;
+        for (int R = 1; R <= 16; R <<= 1) {
+            if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
             float ms = 0.f;
-            if ((rc = timed(at, p, want_grad, &ms)) != PHK_OK) return rc;
-            if (best_ms == 0.f || ms < best_ms) {
-                best_ms = ms;
-                best = p;
+            if ((rc = time_launch([&] { return l.fwd(R, T, h->nrm, want_grad, at, 256, st); }, &ms)) != PHK_OK) return rc;
+            if (!bf || ms < tf) { tf = ms; bf = R; }
+        }
+        if (want_grad) {
+            for (int R = 1; R <= 16; R <<= 1) {
+                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+                float ms = 0.f;
+                if (!h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
+                if ((rc = time_launch([&] { return l.bwd(R, T, h->nrm, at, 0, 256, st); }, &ms)) != PHK_OK) return rc;
+                if (!bb || ms < tb) { tb = ms; bb = R; }
             }
+        } else {
+            bb = bf;
+        }
+        if (bf && bb && (best_ms == 0.f || tf + tb < best_ms)) {
+            best_ms = tf + tb;
+            best = Plan();
+            best.T = T;
+            best.R = bb;
+            best.R1 = bf;
         }
     }
     // segmented plan: only worth a look where the serial sweep cannot fill the chip
@@ -538,7 +568,7 @@ int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, 
     if (segmented) *segmented = p.segmented;
     if (R) *R = p.R;
     if (T) *T = p.T;
-    if (R_forward) *R_forward = p.segmented ? p.R1 : p.R;
+    if (R_forward) *R_forward = p.R1 ? p.R1 : p.R;
     if (R_scan) *R_scan = p.segmented ? p.R2 : 0;
     return PHK_OK;
 }
