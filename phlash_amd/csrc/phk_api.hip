@@ -390,10 +390,22 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             }
             if (b2 == 0.f || ms < b2) { b2 = ms; sp.R2 = R; }
         }
-        float seg_ms = 0.f;
-        if ((rc = timed(a, sp, true, &seg_ms)) != PHK_OK) return rc;
+        // the segment sweep is throughput-bound and its parallelism depends on L: try the
+        // variants around the static choice at full length
         const float serial_full = best_ms * (float)h->L / (float)tune_sites;
-        if (seg_ms < serial_full) best = sp;
+        float seg_best = 0.f;
+        for (int R = 1; R <= 8; R <<= 1) {
+            if (!valid_R(K, R)) continue;
+            Plan cand = sp;
+            cand.R = R;
+            float seg_ms = 0.f;
+            if ((rc = timed(a, cand, true, &seg_ms)) != PHK_OK) return rc;
+            if (seg_best == 0.f || seg_ms < seg_best) {
+                seg_best = seg_ms;
+                sp = cand;
+            }
+        }
+        if (seg_best < serial_full) best = sp;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -53,6 +53,20 @@ def main():
         print(f"auto -> plan={eng.get_plan()} fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall * 1e3:8.2f} ms launches={n} "
               f"-> {work / ((f + b) * 1e-3):.3e} site-particle/s", flush=True)
         return
+    if a.variants.startswith("plan="):  # plan=seg:R:Rf:Rs;seg:R:Rf:Rs...
+        eng.set_autotune(False)
+        for spec in a.variants[5:].split(";"):
+            seg, R, Rf, Rs = (int(x) for x in spec.split(":"))
+            eng.set_plan(seg, R=R, T=8, R_forward=Rf, R_scan=Rs)
+            for rep in range(a.reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ll, g = eng.run(p, inds, warmup=a.W, grad=True)
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+                f, b, n = eng.last_timing()
+            print(f"plan {spec}: fwd={f:8.2f} ms bwd={b:8.2f} ms wall={wall * 1e3:8.2f} ms -> {work / ((f + b) * 1e-3):.3e}", flush=True)
+        return
     for v in a.variants.split(","):
         R, T, NRM = (int(x) for x in v.split(":"))
         try:
