@@ -473,8 +473,17 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     double llW = 0.0, invW = 0.0;
     const int64_t nblk = (A.Ltot + T - 1) / T;
     real* ck = (real*)A.ckpt;
+    // observation words are requested one word (16 sites) ahead: a load issued at the top of the
+    // block that consumes it would expose a full L2 round trip every T sites
+    const int64_t nwords = (A.Ltot + 15) >> 4;
+    uint32_t wcur = 0, wnext = nwords > 0 ? words[0] : 0u;
     for (int64_t blk = 0; blk < nblk; ++blk) {
         const int64_t t0 = blk * T;
+        if ((t0 & 15) == 0) {
+            wcur = wnext;
+            const int64_t nx = (t0 >> 4) + 1;
+            wnext = words[nx < nwords ? nx : nwords - 1];
+        }
         if constexpr (CKPT) {
             if (active) {
                 real* dst = ck + (blk * nseq + seq) * K + rank * SPL;
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         if constexpr (CKPT) {
             if (active && rank == 0 && A.seg_blocks > 0 && blk % A.seg_blocks == 0) A.eseg[(blk / A.seg_blocks) * nseq + seq] = E;
         }
-        const uint32_t codes = block_codes(words, t0);
+        const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
         if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
@@ -608,13 +617,24 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     int since_flush = 0;
 
     real anext[SPL];
+    // observation words, one word ahead of the (descending) block that needs it
+    int64_t widx = -1;
+    uint32_t wcur = 0, wprev = 0;
     if (blk_hi > blk_lo) {
         const real* src = ck + ((blk_hi - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) anext[i] = src[i];
+        widx = ((blk_hi - 1) * T) >> 4;
+        wcur = words[widx];
+        wprev = words[widx > 0 ? widx - 1 : 0];
     }
     for (int64_t blk = blk_hi - 1; blk >= blk_lo; --blk) {
         const int64_t t0 = blk * T;
+        if ((t0 >> 4) != widx) {  // stepped into the previous word
+            widx = t0 >> 4;
+            wcur = wprev;
+            wprev = words[widx > 0 ? widx - 1 : 0];
+        }
         V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
         real sc[T / NRM];
 #pragma unroll
@@ -629,7 +649,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
 #pragma unroll
             for (int i = 0; i < SPL; ++i) anext[i] = src[i];
         }
-        const uint32_t codes = block_codes(words, t0);
+        const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
         if (bwd_straight_line<real, K, R, T>() && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
             // full block, no warm-up boundary inside: straight-line code for all 2T site steps.
@@ -795,7 +815,10 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
     int F = 0;
     const int64_t nw = (A.Ltot + 15) / 16;
+    uint32_t wnext = nw > 0 ? words[nw - 1] : 0u;  // one word ahead of its use
     for (int64_t w = nw - 1; w >= 0; --w) {
+        const uint32_t codes = wnext;
+        wnext = words[w > 0 ? w - 1 : 0];
         const int64_t t_hi = (w + 1) * 16;  // first site to the right of this word
         if (t_hi < A.Ltot && t_hi % seg_sites == 0) {
             const int64_t sb = t_hi / seg_sites;
@@ -806,7 +829,6 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
                 if (rank == 0) fseg_out[sb * nseq + seq] = F;
             }
         }
-        const uint32_t codes = words[w];
         const int ns = (int)((A.Ltot - w * 16) < 16 ? (A.Ltot - w * 16) : 16);
         if (ns == 16) {
             V ec[NP];
