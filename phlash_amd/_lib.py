@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphlash_hip.so")
+# PHK_LIB (developer A/B builds only) may point at another build of the same library
+LIB_PATH = os.environ.get("PHK_LIB") or os.path.join(_HERE, "libphlash_hip.so")
 
 PHK_OK, PHK_EINVAL, PHK_ENOMEM, PHK_EHIP, PHK_EUNSUPPORTED = 0, 1, 2, 3, 4
 
