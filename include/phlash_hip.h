@@ -107,7 +107,8 @@ int phk_set_autotune(phk_handle* h, int on);
  * chunks), -1 = automatic (default; the autotuner times both where the batch is small). */
 int phk_set_backward_mode(phk_handle* h, int mode);
 /* Force a complete plan (segmented = -1 returns to automatic).  Serial: (R, T).  Segmented: R for
- * the segment sweep, R_forward for the forward kernel, R_scan for the beta scan; T is 8. */
+ * the segment sweep, R_forward for the forward kernel, R_scan for the beta scan; T (8 or 16) is
+ * shared by the forward kernel and the sweep. */
 int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int R_scan);
 /* The plan the last phk_loglik ran with. */
 int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, int* R_scan);

@@ -62,7 +62,8 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int DEFAULT_NRM = 4;   // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
-constexpr int SEG_BLOCKS = 64;   // blocks per segment of the segmented backward (512 sites at T = 8)
+constexpr int SEG_SITES = 512;    // sites per segment of the segmented backward
+constexpr int seg_blocks(int T) { return SEG_SITES / T; }  // 64 blocks at T = 8, 32 at T = 16
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 
 struct DevBuf {
@@ -180,8 +181,8 @@ int largest_R(const phk_handle* h, int T) {
 
 int64_t n_units(const phk_handle* h, int T, int64_t W) {
     const int64_t nblk = (h->L + T - 1) / T;
-    const int64_t nseg = (nblk + SEG_BLOCKS - 1) / SEG_BLOCKS;
-    const int64_t segW = W > 0 ? ((W - 1) / T) / SEG_BLOCKS : 0;
+    const int64_t nseg = (nblk + seg_blocks(T) - 1) / seg_blocks(T);
+    const int64_t segW = W > 0 ? ((W - 1) / T) / seg_blocks(T) : 0;
     return nseg - segW;
 }
 
@@ -224,7 +225,7 @@ int ensure_scratch(phk_handle* h, int64_t nseq) {
     const int K = h->K;
     const size_t rs = real_size(h);
     const int64_t nblk8 = (h->L + 7) / 8;
-    const int64_t nsegp = (nblk8 + SEG_BLOCKS - 1) / SEG_BLOCKS + 1;
+    const int64_t nsegp = (nblk8 + seg_blocks(8) - 1) / seg_blocks(8) + 1;
     int rc;
     if ((rc = h->ckpt.ensure((size_t)nseq * nblk8 * K * rs)) != PHK_OK) return rc;
     if ((rc = h->aux.ensure((size_t)nseq * sizeof(phk::SeqAux))) != PHK_OK) return rc;
@@ -245,7 +246,7 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     const int nt = 256;
     const int64_t nseq = a.B * a.S;
     hipError_t e;
-    a.seg_blocks = SEG_BLOCKS;
+    a.seg_blocks = seg_blocks(plan.T);
     if (!want_grad) {
         e = l.fwd(plan.R1 && !plan.segmented ? plan.R1 : plan.R, plan.T, h->nrm, false, a, nt, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
@@ -263,7 +264,7 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         return PHK_OK;
     }
     // segmented: the beta scan needs nothing from the forward kernel -> second stream
-    const int64_t seg_sites = (int64_t)SEG_BLOCKS * plan.T;
+    const int64_t seg_sites = SEG_SITES;
     HIP_TRY(hipEventRecord(h->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
@@ -326,8 +327,8 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         }
         return PHK_OK;
     };
-    at.seg_blocks = SEG_BLOCKS;
     for (int T = 8; T <= 16; T += 8) {
+        at.seg_blocks = seg_blocks(T);
         // the forward and the backward kernel are timed separately (any forward variant leaves valid
         // checkpoints for any backward variant of the same T) and the fastest of each is kept
         int bf = 0, bb = 0;
@@ -360,52 +361,49 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     // segmented plan: only worth a look where the serial sweep cannot fill the chip
     const int64_t units = n_units(h, 8, proto.W);
     if (want_grad && h->L >= 4 * TUNE_SITES && units >= 8 && nseq * best.R / 64 < 1024) {
-        Plan sp;
-        sp.segmented = 1;
-        sp.T = 8;
-        sp.R = throughput_R(h, nseq * units, 8, 2);
-        // latency-bound pair: fastest forward-with-checkpoints R1 and fastest beta-scan R2
-        float b1 = 0.f, b2 = 0.f;
+        const float serial_full = best_ms * (float)h->L / (float)tune_sites;
+        // the beta scan does not depend on T: fastest R2 on the truncated problem
+        int R2 = 0;
+        float b2 = 0.f;
         for (int R = 1; R <= 16; R <<= 1) {
             if (!valid_R(K, R)) continue;
             float ms = 0.f;
-            for (int rep = 0; rep < 2; ++rep) {
-                HIP_TRY(hipEventRecord(e0, st));
-                phk::KArgs k1 = at;
-                k1.seg_blocks = SEG_BLOCKS;
-                hipError_t e = l.fwd(R, 8, h->nrm, true, k1, 256, st);
-                if (e != hipSuccess) return fail(PHK_EHIP, "autotune forward launch: %s", hipGetErrorString(e));
-                HIP_TRY(hipEventRecord(e1, st));
-                HIP_TRY(hipEventSynchronize(e1));
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-            }
-            if (b1 == 0.f || ms < b1) { b1 = ms; sp.R1 = R; }
-            for (int rep = 0; rep < 2; ++rep) {
-                HIP_TRY(hipEventRecord(e0, st));
-                hipError_t e = l.bscan(R, h->nrm, at, (int64_t)SEG_BLOCKS * 8, h->bseg.p, (int32_t*)h->fseg.p, 256, st);
-                if (e != hipSuccess) return fail(PHK_EHIP, "autotune beta-scan launch: %s", hipGetErrorString(e));
-                HIP_TRY(hipEventRecord(e1, st));
-                HIP_TRY(hipEventSynchronize(e1));
-                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-            }
-            if (b2 == 0.f || ms < b2) { b2 = ms; sp.R2 = R; }
+            if ((rc = time_launch([&] { return l.bscan(R, h->nrm, at, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, 256, st); }, &ms)) != PHK_OK) return rc;
+            if (!R2 || ms < b2) { b2 = ms; R2 = R; }
         }
-        // the segment sweep is throughput-bound and its parallelism depends on L: try the
-        // variants around the static choice at full length
-        const float serial_full = best_ms * (float)h->L / (float)tune_sites;
         float seg_best = 0.f;
-        for (int R = 1; R <= 8; R <<= 1) {
-            if (!valid_R(K, R)) continue;
-            Plan cand = sp;
-            cand.R = R;
-            float seg_ms = 0.f;
-            if ((rc = timed(a, cand, true, &seg_ms)) != PHK_OK) return rc;
-            if (seg_best == 0.f || seg_ms < seg_best) {
-                seg_best = seg_ms;
-                sp = cand;
+        Plan seg_plan;
+        for (int T = 8; T <= 16; T += 8) {
+            // latency-bound forward kernel: fastest R1 for this T on the truncated problem
+            int R1 = 0;
+            float b1 = 0.f;
+            at.seg_blocks = seg_blocks(T);
+            for (int R = 1; R <= 16; R <<= 1) {
+                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+                float ms = 0.f;
+                if ((rc = time_launch([&] { return l.fwd(R, T, h->nrm, true, at, 256, st); }, &ms)) != PHK_OK) return rc;
+                if (!R1 || ms < b1) { b1 = ms; R1 = R; }
+            }
+            if (!R1) continue;
+            // the segment sweep is throughput-bound and its parallelism depends on L: time the whole
+            // plan at full length for every sweep variant
+            for (int R = 1; R <= 8; R <<= 1) {
+                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+                Plan cand;
+                cand.segmented = 1;
+                cand.T = T;
+                cand.R = R;
+                cand.R1 = R1;
+                cand.R2 = R2;
+                float seg_ms = 0.f;
+                if ((rc = timed(a, cand, true, &seg_ms)) != PHK_OK) return rc;
+                if (seg_best == 0.f || seg_ms < seg_best) {
+                    seg_best = seg_ms;
+                    seg_plan = cand;
+                }
             }
         }
-        if (seg_best < serial_full) best = sp;
+        if (seg_best > 0.f && seg_best < serial_full) best = seg_plan;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -563,7 +561,7 @@ int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int 
     Plan p;
     p.segmented = segmented ? 1 : 0;
     p.R = R;
-    p.T = p.segmented ? 8 : T;
+    p.T = T;
     p.R1 = R_forward;
     p.R2 = R_scan;
     if (!valid_R(h->K, p.R) || !valid_T(h->K, p.R, p.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
@@ -720,7 +718,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.grad_dlog = grad_dlog;
         a.eblk = (int16_t*)h->eblk.p;
         a.eseg = (int32_t*)h->eseg.p;
-        a.seg_blocks = SEG_BLOCKS;
+        a.seg_blocks = seg_blocks(8);  // enqueue() sets the plan's value
         a.bseg = h->bseg.p;
         a.fseg = (const int32_t*)h->fseg.p;
         a.bpi = (double*)h->bpi.p;

@@ -79,20 +79,16 @@ constexpr int ROW_HALF_MIRROR = 0x141;
 // ---------------------------------------------------------------------------------------------
 template <typename real, int R>
 struct Group {
-    real up1, up2, up3, up4, up8;  // 1.0 where rank >= n, else 0.0
-    real dn1, dn2, dn3, dn4, dn8;  // 1.0 where rank + n < R, else 0.0
+    real up1, up2, up3;  // 1.0 where rank >= n, else 0.0   (shifts by 4 and 8 are masked by DPP itself)
+    real dn1, dn2, dn3;  // 1.0 where rank + n < R, else 0.0
 
     __device__ __forceinline__ void init(int rank) {
         up1 = rank >= 1 ? real(1) : real(0);
         up2 = rank >= 2 ? real(1) : real(0);
         up3 = rank >= 3 ? real(1) : real(0);
-        up4 = rank >= 4 ? real(1) : real(0);
-        up8 = rank >= 8 ? real(1) : real(0);
         dn1 = rank + 1 < R ? real(1) : real(0);
         dn2 = rank + 2 < R ? real(1) : real(0);
         dn3 = rank + 3 < R ? real(1) : real(0);
-        dn4 = rank + 4 < R ? real(1) : real(0);
-        dn8 = rank + 8 < R ? real(1) : real(0);
     }
 
     // all-reduce: every lane of the group gets the same bits (each step adds a commutative pair)
@@ -389,9 +385,6 @@ struct Lane {
 };
 
 // 2-bit observation codes: 16 sites per dword; site t of a row -> bits [2*(t%16), +2) of word t/16
-__device__ __forceinline__ uint32_t block_codes(const uint32_t* __restrict__ words, int64_t t0) {
-    return words[t0 >> 4] >> (2 * (int)(t0 & 15));
-}
 
 struct SeqAux {      // written by the forward kernel, read by the backward kernel
     double inv_end;  // 1 / sum(alpha) after the last site (scaled state)

@@ -233,6 +233,13 @@ def test_segmented_backward(K, dbl, rng):
         ll_ref, g_ref = cport.batch(P, data, inds, W)
         _check(ll, g, ll_ref, g_ref, dbl)
     assert plan["R_forward"] != plan["R"]  # the kernels really ran as different variants
+    # checkpoint block 16 (32 blocks per 512-site segment)
+    eng.set_plan(1, R=4 if K == 16 else 16, T=16, R_forward=8 if K == 16 else 16, R_scan=4)
+    for W in (0, 100, 600):
+        ll, g = _run(eng, P, inds, W)
+        assert eng.get_plan()["T"] == 16
+        ll_ref, g_ref = cport.batch(P, data, inds, W)
+        _check(ll, g, ll_ref, g_ref, dbl)
     # same lanes-per-sequence everywhere, every rescale interval, d/dlog output
     eng.set_plan(-1)
     eng.set_backward_mode(1)
