@@ -16,11 +16,22 @@ import torch
 from . import _lib
 
 
+COMPILED_K = (4, 8, 16, 32, 64)
+
+
 class HipEngine:
+    """K hidden states.  The kernels are compiled for K in {4, 8, 16, 32, 64}; any other K <= 64 runs
+    on the next compiled size with unreachable padding states (zero transition / initial mass,
+    emission 1), which changes nothing: their alpha stays exactly 0."""
+
     def __init__(self, K: int, data, double_precision: bool = False, device: int = 0):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: phlash_amd needs an MI355X (there is no CPU fallback)")
+        self.K_user = int(K)
+        if not 2 <= self.K_user <= COMPILED_K[-1]:
+            raise NotImplementedError(f"K={K} outside [2, {COMPILED_K[-1]}]")
+        K = min(k for k in COMPILED_K if k >= self.K_user)
         self.K = int(K)
         self.double_precision = bool(double_precision)
         self.device = torch.device("cuda", int(device))
@@ -107,7 +118,11 @@ class HipEngine:
         inds int64 [S] on the device.  Returns ll [B, S] float64 and, if ``grad``, d ll/d params
         [B, S, 7, K] in the handle's float type (``dlog``: theta * d ll/d theta)."""
         assert params.is_cuda and inds.is_cuda and params.device == self.device
-        assert params.ndim == 4 and params.shape[2] == 7 and params.shape[3] == self.K, params.shape
+        assert params.ndim == 4 and params.shape[2] == 7 and params.shape[3] == self.K_user, params.shape
+        if self.K_user != self.K:  # pad to the compiled size: rows b,d,u,v,pi with 0, emission rows with 1
+            pad = torch.zeros(params.shape[:3] + (self.K - self.K_user,), dtype=params.dtype, device=params.device)
+            pad[:, :, 4:6, :] = 1.0
+            params = torch.cat([params, pad], -1)
         assert inds.ndim == 1 and inds.dtype == torch.int64
         B, Sp = params.shape[0], params.shape[1]
         S = inds.shape[0]
@@ -124,4 +139,6 @@ class HipEngine:
             ll.data_ptr(), g.data_ptr() if grad else None, int(bool(dlog)), ctypes.c_void_p(stream),
         )
         _lib.check(rc)
+        if grad and self.K_user != self.K:
+            g = g[..., : self.K_user]
         return (ll, g) if grad else ll

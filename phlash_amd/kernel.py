@@ -61,7 +61,8 @@ class PSMCKernel:
     """PSMC likelihood kernel on one MI355X.
 
     Args (reference: gpu.py:328-350):
-        M: number of hidden states (4, 8, 16, 32 or 64; the reference is tuned for 16).
+        M: number of hidden states, 2..64 (compiled sizes 4, 8, 16, 32, 64; others are padded to the
+            next one; the reference is tuned for 16).
         data: int8 [N, L] het matrix, values -1 (missing), 0, 1 (larger counts are clipped to 1).
         double_precision: float64 kernels instead of float32.
         num_gpus: accepted for signature compatibility.  One kernel object drives one GPU; scale

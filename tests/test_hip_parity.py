@@ -176,7 +176,7 @@ def test_errors(data):
     from phlash_amd.engine import HipEngine
 
     with pytest.raises(NotImplementedError):
-        HipEngine(7, data)
+        HipEngine(65, data)
     bad = data.copy()
     bad[3] = -1
     with pytest.raises(AssertionError):
@@ -272,3 +272,17 @@ def test_segmented_short_rows_fall_back_to_one_unit(rng):
         ll, g = _run(eng, P, np.arange(3), W)
         ll_ref, g_ref = cport.batch(P, data, np.arange(3), W)
         _check(ll, g, ll_ref, g_ref, True)
+
+
+@pytest.mark.parametrize("K", [5, 20, 48])
+def test_uncompiled_K_runs_padded(K, rng):
+    """Any K <= 64: states beyond K are unreachable padding in the next compiled size."""
+    data = (rng.uniform(size=(4, 600)) < 0.08).astype(np.int8)
+    data[:, 0] = 0
+    eng = _engine(K, data, True)
+    assert eng.K >= K and eng.K_user == K
+    P = _params(K, 2, 1, seed=9)
+    ll, g = _run(eng, P, np.arange(4), 50)
+    assert g.shape[-1] == K
+    ll_ref, g_ref = cport.batch(P, data, np.arange(4), 50)
+    _check(ll, g, ll_ref, g_ref, True)
