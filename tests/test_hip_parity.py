@@ -286,3 +286,22 @@ def test_uncompiled_K_runs_padded(K, rng):
     assert g.shape[-1] == K
     ll_ref, g_ref = cport.batch(P, data, np.arange(4), 50)
     _check(ll, g, ll_ref, g_ref, True)
+
+
+def test_tiny_emissions_need_per_site_rescaling():
+    """Emission probabilities at the reference's 1e-20 clip floor on a run of het sites: the mass
+    shrinks by 1e-11 per site here, so four unscaled sites underflow float32.  Per-site rescaling
+    (interval 1, the reference's schedule) stays exact; float64 is safe at any interval."""
+    K = 16
+    P = _params(K, 1, 1, seed=0)
+    P[0, 0, 5] = 1e-11  # emis1
+    P[0, 0, 4] = 1.0 - 1e-11
+    data = np.ones((1, 64), dtype=np.int8)
+    ll_ref, g_ref = cport.batch(P, data, [0], 0)
+    e32 = _engine(K, data, False)
+    e32.set_rescale_interval(1)
+    ll, g = _run(e32, P, np.arange(1), 0)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-5)
+    e64 = _engine(K, data, True)
+    ll, g = _run(e64, P, np.arange(1), 0)
+    _check(ll, g, ll_ref, g_ref, True)
