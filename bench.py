@@ -152,6 +152,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
+    assert not kern._eng.underflow_risk(), "the rescale interval was too long for these particles"
 
     if rank == 0:
         work_per_step = world * B * S * L

@@ -117,6 +117,11 @@ int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, 
  * (hmm.py:77-79); larger intervals do the same arithmetic with fewer rescales and are safe while
  * nrm consecutive sites cannot shrink the total mass below the float range. */
 int phk_set_rescale_interval(phk_handle* h, int nrm);
+/* With nrm > 1 the forward kernel raises a sticky flag when a rescale finds the total mass below
+ * 2^-64 (float) / 2^-600 (double), i.e. the parameters are extreme enough that the unscaled sites in
+ * between could have lost precision.  Reads (and clears) the flag; synchronises with the work
+ * enqueued before.  The Python host re-evaluates such a call with nrm = 1. */
+int phk_underflow_risk(phk_handle* h, int* flag);
 /* Upper bound for the checkpoint workspace; larger problems are run in particle / chunk slabs. */
 int phk_set_workspace_limit(phk_handle* h, int64_t bytes);
 int64_t phk_workspace_bytes(phk_handle* h);

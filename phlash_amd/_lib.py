@@ -30,6 +30,7 @@ SIGNATURES = {
     "phk_set_variant": (_i, [_vp, _i, _i]),
     "phk_get_variant": (_i, [_vp, _i64, _i64, _ip, _ip]),
     "phk_set_rescale_interval": (_i, [_vp, _i]),
+    "phk_underflow_risk": (_i, [_vp, _ip]),
     "phk_set_autotune": (_i, [_vp, _i]),
     "phk_set_backward_mode": (_i, [_vp, _i]),
     "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),

@@ -111,7 +111,7 @@ struct phk_handle {
     int K = 0, device = 0, dbl = 0;
     int64_t N = 0, L = 0, Lw = 0;
     uint32_t* packed = nullptr;
-    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, tune_ll, tune_grad;
+    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, tune_ll, tune_grad, risk;
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int mode = -1;     // -1 auto, 0 serial, 1 segmented
@@ -457,6 +457,10 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) h->ws_limit = (int64_t)(free_b / 2);
     else h->ws_limit = (int64_t)32 << 30;
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
+    if (h->risk.ensure(sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, sizeof(int)) != hipSuccess) {
+        delete h;
+        return fail(PHK_ENOMEM, "could not allocate the underflow flag");
+    }
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -505,7 +509,7 @@ int phk_destroy(phk_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
-    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->tune_ll, &h->tune_grad})
+    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->tune_ll, &h->tune_grad, &h->risk})
         b->release();
     if (h->packed) (void)hipFree(h->packed);
     delete h;
@@ -580,6 +584,14 @@ int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, 
     if (T) *T = p.T;
     if (R_forward) *R_forward = p.R1 ? p.R1 : p.R;
     if (R_scan) *R_scan = p.segmented ? p.R2 : 0;
+    return PHK_OK;
+}
+
+int phk_underflow_risk(phk_handle* h, int* flag) {
+    if (!h || !flag) return fail(PHK_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(flag, h->risk.p, sizeof(int), hipMemcpyDeviceToHost));  // waits for the work before it
+    if (*flag) HIP_TRY(hipMemset(h->risk.p, 0, sizeof(int)));
     return PHK_OK;
 }
 
@@ -722,6 +734,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.bseg = h->bseg.p;
         a.fseg = (const int32_t*)h->fseg.p;
         a.bpi = (double*)h->bpi.p;
+        a.risk = (int*)h->risk.p;
         return a;
     };
 

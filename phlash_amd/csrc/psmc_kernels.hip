@@ -417,7 +417,16 @@ struct KArgs {
     const void* bseg;        // [nseg+1, B*S, K] real: scaled b*_t = A(e.b*) recursion at segment starts
     const int32_t* fseg;     // [nseg+1, B*S] its exponents
     double* bpi;             // [B*S, K] d ll / d pi (segmented mode; the serial kernel writes grad itself)
+    int* risk;               // set to 1 if a rescale ever found the mass below 2^RISK_EXP (see below)
 };
+
+// With rescaling only every NRM-th site the unscaled mass must survive NRM sites.  A rescale that
+// finds the total below 2^RISK_EXP means the parameters are extreme enough (emissions near the
+// reference's 1e-20 clip on a run of such sites) that float32 could have lost states or underflowed in
+// between; the forward kernel then raises a flag and the host re-evaluates with per-site rescaling
+// (NRM = 1, the reference's schedule), which is always safe.
+constexpr int RISK_EXP_F32 = -64;
+constexpr int RISK_EXP_F64 = -600;
 
 constexpr double LN2 = 0.693147180559945309417232121458;
 
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
 
     int E = 0;
+    int ex_min = 0;  // smallest exponent any rescale of this sequence removed
     double llW = 0.0, invW = 0.0;
     const int64_t nblk = (A.Ltot + T - 1) / T;
     real* ck = (real*)A.ckpt;
@@ -500,7 +510,9 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                 V en[NP];  // next site's emission row is in flight while this site computes
                 if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
                 real sc;
-                E += lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
+                const int ex = lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
+                E += ex;
+                if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
                 if (i + 1 < T) {
 #pragma unroll
                     for (int h = 0; h < NP; ++h) ec[h] = en[h];
@@ -514,7 +526,9 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                     real sc;
                     V e[NP];
                     lane.emis((codes >> (2 * i)) & 3, e);
-                    E += lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
+                    const int ex = lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
+                    E += ex;
+                    if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
                     if (t0 + i + 1 == A.W) {
                         const double cW = (double)lane.total(a);
                         llW = log(cW) + (double)E * LN2;
@@ -528,6 +542,9 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         }
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
+    if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
+        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || !(cend > 0.0)))
+        atomicOr(A.risk, 1);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
         if constexpr (CKPT) {

@@ -71,6 +71,14 @@ class HipEngine:
 
     def set_rescale_interval(self, nrm: int = 0):
         _lib.check(_lib.load().phk_set_rescale_interval(self._h, int(nrm)))
+        self._nrm = int(nrm)
+
+    def underflow_risk(self) -> bool:
+        """True if a call since the last query ran into parameters too extreme for rescaling only
+        every few sites (synchronises).  The caller should re-evaluate with set_rescale_interval(1)."""
+        f = ctypes.c_int()
+        _lib.check(_lib.load().phk_underflow_risk(self._h, ctypes.byref(f)))
+        return bool(f.value)
 
     def set_autotune(self, on: bool):
         _lib.check(_lib.load().phk_set_autotune(self._h, int(bool(on))))

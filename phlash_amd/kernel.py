@@ -33,6 +33,18 @@ def _as_tensor(a, device):
     return torch.as_tensor(np.asarray(a, dtype=np.float64), dtype=F64, device=device)
 
 
+def _run_guarded(kern, *args, **kw):
+    """engine.run with the safety net of the rescale interval: if the forward kernel reports that the
+    parameters are too extreme for rescaling every few sites only, switch this kernel object to
+    per-site rescaling (the reference's schedule, hmm.py:77-79) for good and evaluate again."""
+    out = kern._eng.run(*args, **kw)
+    if kern._eng.underflow_risk():
+        warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
+        kern._eng.set_rescale_interval(1)
+        out = kern._eng.run(*args, **kw)
+    return out
+
+
 class _LogLik(torch.autograd.Function):
     """ll = kernel(params); backward = cotangent * stored d ll / d params (gpu.py:441-472: the fwd
     rule runs the gradient kernel and the bwd rule scales the stored derivative)."""
@@ -41,11 +53,11 @@ class _LogLik(torch.autograd.Function):
     def forward(ctx, params, kern, inds, need_grad):
         # params [B, S|1, 7, K] float64 on the device
         if need_grad:
-            ll, g = kern._eng.run(params, inds, warmup=kern.overlap, grad=True, dlog=False)
+            ll, g = _run_guarded(kern, params, inds, warmup=kern.overlap, grad=True, dlog=False)
             ctx.save_for_backward(g)
             ctx.bcast = params.shape[1] == 1 and inds.shape[0] > 1
         else:
-            ll = kern._eng.run(params, inds, warmup=kern.overlap, grad=False)
+            ll = _run_guarded(kern, params, inds, warmup=kern.overlap, grad=False)
         return ll
 
     @staticmethod
@@ -168,9 +180,9 @@ class PSMCKernel:
         pa, inds, added_B, added_S = self._prepare(pp, index)
         with torch.no_grad():
             if grad:
-                ll, g = self._eng.run(pa, inds, warmup=self.overlap, grad=True, dlog=True)
+                ll, g = _run_guarded(self, pa, inds, warmup=self.overlap, grad=True, dlog=True)
             else:
-                ll = self._eng.run(pa, inds, warmup=self.overlap, grad=False)
+                ll = _run_guarded(self, pa, inds, warmup=self.overlap, grad=False)
         ll = self._strip(ll, added_B, added_S)
         if want_numpy:
             ll = ll.cpu().numpy()
@@ -185,13 +197,25 @@ class PSMCKernel:
     def value_and_grad(self, pp: PSMCParams, inds: torch.Tensor, reduce_chunks: bool = True):
         """One particle population against a minibatch: pp fields [B, M] -> (ll, d ll / d params).
         With ``reduce_chunks`` the sum over the S chunks is taken here (ll [B], grad [B, 7, M]
-        float64) -- the quantity model.log_density needs (model.py:57 ``.sum()``)."""
+        float64) -- the quantity model.log_density needs (model.py:57 ``.sum()``).  Asynchronous: no
+        host synchronisation, hence no underflow check here; ``fit`` calls ``check_rescaling()`` once per
+        iteration, where it synchronises anyway."""
         pa = torch.stack([_as_tensor(a, self.device) for a in pp], -2)[:, None]
         with torch.no_grad():
             ll, g = self._eng.run(pa, inds, warmup=self.overlap, grad=True, dlog=False)
         if reduce_chunks:
             return ll.sum(1), g.sum(1, dtype=F64)
         return ll, g
+
+
+    def check_rescaling(self) -> bool:
+        """True (after switching to per-site rescaling) if an evaluation since the last check hit
+        parameters too extreme for the current rescale interval; the caller should redo that step."""
+        if self._eng.underflow_risk():
+            warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
+            self._eng.set_rescale_interval(1)
+            return True
+        return False
 
 
 def get_kernel(M: int, data, double_precision: bool = False, **kw) -> PSMCKernel:

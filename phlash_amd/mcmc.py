@@ -202,6 +202,16 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             xs = state.particles.detach().requires_grad_(True)
             lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
             (g,) = torch.autograd.grad(lp.sum(), xs)
+        if train_kern.check_rescaling():  # extreme particle: the kernel now rescales every site; redo
+            if by_particles:
+                _, g = parallel.particle_sharded_value_and_grad(
+                    lambda xl: _log_density_population(xl, template, c_train, train_kern, inds, afs, afs_transform,
+                                                       reduce=False),
+                    state.particles)
+            else:
+                xs = state.particles.detach().requires_grad_(True)
+                lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
+                (g,) = torch.autograd.grad(lp.sum(), xs)
         state = svgd.step(state, g, lr)
         assert bool(torch.isfinite(state.particles).all())  # mcmc.py:281-285
         if elpd is not None and i % 10 == 0:

@@ -305,3 +305,19 @@ def test_tiny_emissions_need_per_site_rescaling():
     e64 = _engine(K, data, True)
     ll, g = _run(e64, P, np.arange(1), 0)
     _check(ll, g, ll_ref, g_ref, True)
+    # with the default interval the forward kernel flags the call, and the plugin surface re-runs it
+    e4 = _engine(K, data, False)
+    assert not e4.underflow_risk()
+    _run(e4, P, np.arange(1), 0)
+    assert e4.underflow_risk() and not e4.underflow_risk()  # raised once, cleared by the query
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.params import PSMCParams
+
+    kern = get_kernel(K, data, False)
+    with pytest.warns(UserWarning, match="per-site rescaling"):
+        ll = kern(PSMCParams(*(P[0, 0, i] for i in range(7))), np.int64(0), grad=False)
+    np.testing.assert_allclose(ll, ll_ref[0, 0], rtol=1e-5)
+    # ordinary parameters never raise the flag
+    e4 = _engine(K, data, False)
+    _run(e4, _params(K, 2, 1, seed=1), np.arange(1), 0)
+    assert not e4.underflow_risk()
