@@ -239,3 +239,20 @@ def test_fit_recovers_a_known_size_history():
     assert 0.35 < post < 0.7, f"posterior geometric-mean rate in the middle epochs {post:.3f}, truth 0.5"
     rot = np.mean([dm.rho / dm.theta for dm in res])
     assert 0.5 < rot < 2.0, f"rho/theta {rot:.2f}, truth 1"
+
+
+def test_fit_with_afs_term_and_test_contig():
+    """fit() with a 10-haplotype frequency spectrum (AFS multinomial term, model.py:58-70), two diploid
+    rows per contig and a held-out contig for the ELPD early stop (mcmc.py:213-238, 287-304)."""
+    import phlash_amd
+    from phlash_amd.data import RawContig
+    from phlash_amd.synth import simulate_chunks
+
+    het = simulate_chunks(16, 6, 12_000, seed=2)
+    afs = np.array([400.0, 180, 120, 90, 70, 60, 50, 45, 40])  # ~ 1/b
+    ctgs = [RawContig(het[2 * i : 2 * i + 2], afs, 100) for i in range(3)]
+    res = phlash_amd.fit(ctgs[1:], test_data=ctgs[0], niter=25, num_particles=12, chunk_size=3000, overlap=200,
+                         minibatch_size=4, progress=False, elpd_cutoff=5)
+    assert len(res) == 12
+    c = np.stack([np.asarray(dm.eta.c) for dm in res])
+    assert np.isfinite(c).all() and (c > 0).all()
