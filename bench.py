@@ -216,7 +216,7 @@ def main():
                 },
             },
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU leg (and the parity figure it yields) runs at N = 1 only
             # GPU ll of a bounded sample, then the oracle on the same sample (also the parity figure)
             with torch.no_grad():
                 mcp = template.from_flat(x0.to(dev))
