@@ -196,6 +196,33 @@ def test_errors(data):
         _run(eng, _params(16, 1, 1, 0), np.arange(2), 5000)
 
 
+def test_handles_release_their_device_memory(data):
+    """phk_destroy frees everything the handle owned (gpu.py:153-174): 40 create / evaluate /
+    destroy rounds, with both plans and the tuner, leave the device's free memory where it was."""
+    import torch
+
+    from phlash_amd.engine import HipEngine
+
+    P = _params(16, 6, 1, seed=2)
+    inds = np.arange(10)
+
+    def once(i):
+        eng = HipEngine(16, data, double_precision=bool(i & 1))
+        if i % 4 >= 2:
+            eng.set_backward_mode(1)
+        _run(eng, P, inds, 50)
+        eng.close()
+
+    once(0), once(1), once(2)  # code objects, allocator pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        once(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, f"{(free0 - free1) >> 20} MiB not returned"
+
+
 def test_autotune_picks_a_valid_variant_and_keeps_results(rng):
     data = (rng.uniform(size=(40, 3000)) < 0.05).astype(np.int8)
     eng = _engine(16, data, False)
