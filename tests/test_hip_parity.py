@@ -348,3 +348,63 @@ def test_tiny_emissions_need_per_site_rescaling():
     e4 = _engine(K, data, False)
     _run(e4, _params(K, 2, 1, seed=1), np.arange(1), 0)
     assert not e4.underflow_risk()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shapes_against_the_oracle(seed):
+    """Seeded random draws over everything the launch depends on -- K, float type, particles x
+    chunks (shared or per-chunk parameter blocks), row length, warm-up, missing-data rate, plan
+    (serial variant / segmented with mixed variants / tuner), rescale interval, chunk indices with
+    repeats -- each compared with the float64 oracle on the same inputs."""
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.choice([4, 8, 16, 16, 16, 32, 64]))
+    dbl = bool(rng.integers(2))
+    B, S = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+    N = int(rng.integers(S, S + 5))
+    L = int(rng.choice([1, 2, 7, 8, 9, 31, 64, 500, 1025, 2600]))
+    W = int(rng.integers(0, L + 1)) if rng.integers(2) else 0
+    het = float(rng.choice([0.0, 0.02, 0.1, 0.5]))
+    if het == 0.5 and not dbl:
+        # half the sites heterozygous is so far from any model here that the u / v gradients are
+        # sums cancelling to 1e-6 of their terms: every variant agrees with the others to 1e-5 and
+        # the float64 kernels with the oracle to 5e-10, i.e. float32 keeps 1e-1 (scripts/diag_fuzz.py).
+        # Such data only exercise float64.
+        het = 0.1
+    data = (rng.uniform(size=(N, L)) < het).astype(np.int8)
+    data[rng.uniform(size=data.shape) < float(rng.choice([0.0, 0.01, 0.3]))] = -1
+    data[(data == -1).all(axis=1), 0] = 0  # the kernel object rejects all-missing rows (gpu.py:111-113)
+    inds = rng.integers(0, N, size=S)
+    per_chunk = bool(rng.integers(2))
+    P = _params(K, B, S if per_chunk else 1, seed=seed)
+    if per_chunk:  # make the blocks of a particle really differ between chunks
+        P = P * np.exp(0.02 * rng.standard_normal(P.shape))
+    eng = _engine(K, data, dbl)
+    eng.set_rescale_interval(int(rng.choice([1, 2, 4])))
+    mode = int(rng.integers(4))
+    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= 16]
+    if mode == 0:
+        R = int(rng.choice(Rs))
+        eng.set_variant(R, 16 if (K // R <= 4 and rng.integers(2)) else 8)
+    elif mode == 1:
+        eng.set_plan(1, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=int(rng.choice(Rs)))
+    elif mode == 2:
+        eng.set_plan(0, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
+    # mode 3: the tuner / static rule decides
+    ll, g = _run(eng, P, inds, W)
+    ll_ref, g_ref = cport.batch(P if dbl else P.astype(np.float32).astype(np.float64), data, inds, W)
+    if dbl:
+        _check(ll, g, ll_ref, g_ref, True)
+    else:
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
+        # pi row in the form the reference kernel returns, pi_i * d ll/d pi_i (gpu.py:303-313): on
+        # data far from the model (50 % hets) d ll/d pi_i = P(o | z_0 = i) / P(o) reaches 1e9 for
+        # states of tiny pi_i, and with a warm-up prefix the result is the difference of two such
+        # sweeps -- float32 cannot hold that difference, but weighted by pi_i it is exact to 1e-5
+        g, g_ref = g.copy(), g_ref.copy()
+        g[..., 6, :] *= P[..., 6, :]
+        g_ref[..., 6, :] *= P[..., 6, :]
+        scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
+        scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
+        assert (np.abs(g - g_ref) / scale).max() < 5e-3
+    ll_only = _run(eng, P, inds, W, grad=False)
+    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
