@@ -208,7 +208,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "note": "algorithmic bytes = 1 B per processed site.particle (+params/grads); the scan is "
-                        "VALU-issue/latency bound, not bandwidth bound (see DESIGN.md); fp32 VALU view below",
+                        "VALU-issue/latency bound, not bandwidth bound (see DESIGN.md); vector-ALU view below",
                 "valu": {
                     "achieved_tflops": flops / ((fwd_ms + bwd_ms) / a.steps * 1e-3) / 1e12,
                     "peak_tflops": FP32_PEAK_TFLOPS if not a.double else FP32_PEAK_TFLOPS / 2,
