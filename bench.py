@@ -16,7 +16,9 @@ chunks (cfg3's layout at N = 8 is 5,000 chunks); the particles are shared.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
 "roofline" (dominant kernel = the backward kernel, timed with HIP events on its launch stream) and
-"cpu_baseline" (the oracle's C port on the host cores, bounded sample; a baseline, not the target).
+"cpu_baseline" (the oracle's C port on the host cores, bounded sample; a baseline, not the target);
+and, when oracle/_ref is built, "reference_kernel": the reference's own CUDA gradient kernel compiled
+unmodified for gfx950, timed on the same GPU on a bounded sample of the same rows.
 """
 
 from __future__ import annotations
@@ -50,6 +52,7 @@ def parse():
     ap.add_argument("--overlap", type=int, default=500)
     ap.add_argument("--double", action="store_true", help="float64 kernels (default float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
     ap.add_argument("--variant", default="", help="R:T override for the kernel variant (dev)")
     ap.add_argument("--nrm", type=int, default=0, help="rescale interval override (dev; 0 = library default)")
@@ -82,6 +85,36 @@ def cpu_baseline(P, data, overlap, chunk_size, target_s, ll_gpu):
         "sample": f"{B} particles x {S} chunks x {chunk_size} scored sites (+{overlap} warm-up), float64, "
                   f"forward + reverse-mode gradient, {dt:.1f} s",
     }, float(rel.max())
+
+
+def reference_kernel_leg(P, data, overlap, chunk_size, eng, dbl, max_chunks=80):
+    """The reference's own gradient kernel (src/phlash/gpu.py:575-692, compiled unmodified for gfx950 by
+    oracle/build_ref.py) timed on this GPU on a bounded sample of the same rows, and the log-likelihood
+    of our kernels against the reference's float64 kernel on a smaller sample.  The reference kernel has
+    no warm-up notion: rows of W + L sites are scored whole, so our kernels are run with warm-up 0 here."""
+    from oracle import refcuda
+
+    B, K = P.shape[0], P.shape[-1]
+    if not refcuda.available(K, False) or not refcuda.available(K, True):
+        return None
+    S = int(min(data.shape[0], max_chunks))
+    PB = np.repeat(P[:, None], S, axis=1)
+    _, _, ms = refcuda.call(K, dbl, data, np.arange(S), PB, grad=True, reps=2)
+    Sp = int(min(S, 8))
+    ll_ref, _, _ = refcuda.call(K, True, data, np.arange(Sp), PB[:, :Sp], grad=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Pt = torch.tensor(P[:, None], device=dev, dtype=torch.float64 if dbl else torch.float32)
+    ll = eng.run(Pt, torch.arange(Sp, device=dev), 0, grad=False).cpu().numpy()
+    return {
+        "what": "reference loglik_grad CUDA kernel, unmodified, hipcc gfx950, same GPU, same rows",
+        "value": B * S * chunk_size / (ms * 1e-3),
+        "unit": "site.particle/s",
+        "dtype": "f64" if dbl else "f32",
+        "kernel_ms": ms,
+        "sample": f"{B} particles x {S} chunks x {chunk_size + overlap} sites, grid ({B},{S}) x block (7,{K})",
+        "max_rel_err_loglik_ours_vs_reference_f64_kernel": float(np.abs(ll / ll_ref - 1).max()),
+        "parity_sample": f"{B} particles x {Sp} chunks x {chunk_size + overlap} sites",
+    }
 
 
 def main():
@@ -228,6 +261,13 @@ def main():
             out["cpu_baseline"] = cb
             out["parity"] = {"max_rel_err_loglik_vs_f64_oracle": rel, "bar": 1e-5,
                              "sample": cb["sample"].split(",")[0]}
+            if not a.no_reference_kernel:
+                rk = reference_kernel_leg(pp0.stack().cpu().numpy(), data, W, L, kern._eng, a.double)
+                if rk is not None:
+                    out["reference_kernel"] = rk
+                    out["parity"]["max_rel_err_loglik_vs_reference_f64_kernel"] = rk.pop(
+                        "max_rel_err_loglik_ours_vs_reference_f64_kernel")
+                    out["parity"]["reference_sample"] = rk.pop("parity_sample")
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -13,14 +13,26 @@ file:line it follows (paths relative to the upstream repo jthlab/phlash
 
 PARITY PINNING -- read this before trusting a number
 ----------------------------------------------------
-The reference's own implementation can be neither imported nor compiled in the
-build container or on the GPU box: ``import phlash`` needs jax / jaxlib /
-jax_dataclasses / jaxtyping / loguru / blackjax / optax (all absent, no
-network) and its CUDA kernel is an NVRTC string that needs an NVIDIA driver.
-The reference's tests hold **no numeric golden log-likelihoods or gradients**
-for this path -- every hot-path check there is a self-consistency identity.
-So this oracle is pinned by exactly those identities and known answers
-(``tests/test_oracle_pins.py``), each against the reference test it restates:
+**Kernel level: PINNED to the reference's own code.**  The
+reference's native code for this path is one CUDA C++ translation unit held as a string
+(``KERNEL_SRC``, src/phlash/gpu.py:474-693).  ``oracle/build_ref.py`` reads that text where it lies
+under ``/root/reference`` and compiles it UNMODIFIED with hipcc for gfx950 into ``oracle/_ref/``
+(binaries only, git-ignored; plain CUDA C++ is HIP C++, no stand-in headers are involved).
+``oracle/make_ref_golden.py`` ran those kernels on an MI355X on the reference's test inputs and
+stored their outputs in ``tests/golden/ref_cuda_golden.npz`` (reference-captured).  The float64
+restatement here (numpy loops and C) reproduces the reference's float64 kernels to 1e-15 relative
+on the log-likelihood and 1e-14 (row-scaled) on the gradient (``tests/test_ref_cuda.py``, CPU);
+the HIP kernels are compared with the same vectors and with the reference kernels run live
+(``-m gpu``).  ``tests/golden/ref_afs_golden.npz`` is captured from the reference's
+``src/phlash/afs.py`` (numpy/scipy only; loaded by file path).
+
+**Parameter map and SVGD (rows A11-A14): parity unpinned.**  Everything above the kernel in the
+reference is JAX code: ``import phlash`` needs jax / jaxlib / jax_dataclasses / jaxtyping / loguru
+/ blackjax / optax (all absent, no network), so ``from_dm`` / ``transition_matrix`` /
+``SizeHistory`` cannot be executed here and the reference's tests hold no numeric vectors for
+them -- every check there is an identity or a closed form.  The restatement of those rows is
+pinned by exactly those identities and known answers (``tests/test_oracle_pins.py``), each
+against the reference test it restates:
 
 * ``v @ transition_matrix(dm) == matvec_smc(v, from_dm(dm))``  (tests/test_hmm.py:10-19)
 * ``_expQ(r,c,n) == scipy.linalg.expm(Q)``                      (tests/test_transition.py:21-28)
@@ -32,10 +44,8 @@ So this oracle is pinned by exactly those identities and known answers
   path enumeration; reverse-mode gradient == autograd == finite differences
   (the roles of tests/test_gpu.py:27-64, tests/test_model.py:8-19)
 
-Beyond those identities the numeric values of ll / gradients are
-**parity unpinned** (restatement-derived, not reference-captured); the golden
-vectors in ``tests/golden`` are produced by ``oracle/make_golden.py`` from this
-oracle and are labelled as such.  The SVGD / AMSGrad arithmetic of the
-reference lives in third-party blackjax==1.2.5 / optax==0.2.6 (uv.lock) whose
-sources are not in the reference tree: also parity unpinned.
+``tests/golden/psmc_golden.npz`` (``oracle/make_golden.py``) is restatement-derived and labelled
+as such; it overlaps with the reference-captured file on the conftest inputs, where the two agree
+to 1e-13.  The SVGD / AMSGrad arithmetic of the reference lives in third-party blackjax==1.2.5 /
+optax==0.2.6 (uv.lock) whose sources are not in the reference tree: also parity unpinned.
 """

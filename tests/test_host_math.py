@@ -189,3 +189,26 @@ def test_afs_term_n2_is_zero_and_general_finite():
     esfs = (1 / np.arange(1, 10)) / (1 / np.arange(1, 10)).sum()
     want = float((T @ afs * np.log(T @ esfs)).sum())
     np.testing.assert_allclose(val, want, rtol=1e-6)
+
+
+def test_afs_transforms_match_reference_captured_vectors():
+    """tests/golden/ref_afs_golden.npz holds outputs of the reference's own src/phlash/afs.py
+    (numpy/scipy only, loaded by file path in oracle/make_ref_afs_golden.py)."""
+    import os
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_afs_golden.npz"))
+    n_checked = 0
+    for k in G.files:
+        p = k.split("_")
+        if p[0] == "fold":
+            got = fold_transform(int(p[1]))
+        elif p[0] == "project":
+            got = project_transform(int(p[1]), int(p[2]))
+        elif p[0] == "bws" and p[1] != "in":
+            got = bws_transform(G[f"bws_in_{p[1]}"], float(p[2][1:]))
+        else:
+            continue
+        assert got.shape == G[k].shape, k
+        np.testing.assert_allclose(got, G[k], rtol=1e-10, atol=1e-14, err_msg=k)
+        n_checked += 1
+    assert n_checked >= 50
