@@ -152,6 +152,61 @@ struct Group {
 };
 
 // ---------------------------------------------------------------------------------------------
+// dense 16 x 16 operators for the latency-bound regime (K = 16, one state per lane, float).
+// A batch too small to fill the chip (the reference's production shape: 500 particles x <= 5 chunks)
+// is bound by the latency of ONE site step of ONE sequence times L.  Runs of homozygous sites are
+// the rule (>= 90 % of sites), so the product of 2 (or 4) consecutive hom steps, M_h^2 (M_h^4) with
+// M_h = A diag(emis0), is precomputed per sequence as a dense matrix -- 16 registers per lane, lane i
+// holding column i (forward) or row i (beta scan) -- and applied in ONE step of 16 multiply-adds on
+// lane-broadcast operands (DPP row_newbcast), 6 dependent instructions deep, instead of 2 (4)
+// structured steps of ~11 dependent instructions each.  A wave takes the dense step when all four of
+// its sequences see only hom sites in the group (wave vote); otherwise the structured step.
+// ---------------------------------------------------------------------------------------------
+template <typename real, int K, int R>
+constexpr bool has_dense() { return K == 16 && R == 16 && sizeof(real) == 4; }
+
+template <int J>
+__device__ __forceinline__ float row_share(float x) {  // every lane of a 16-lane row reads lane J of its row
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x150 + J, 0xf, 0xf, true));
+}
+
+// y = sum_j x[lane j of this row] * d[j]: four accumulator chains.  One asm block: the compiler
+// neither fuses the broadcast into v_fmac_f32 nor knows the DPP read-after-VALU-write hazard inside
+// asm, so the block starts with the two wait states that hazard needs (x may be freshly written).
+__device__ __forceinline__ float dense16(float x, const float (&d)[16]) {
+    float c0, c1, c2, c3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+        : "v"(x), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]),
+          "v"(d[9]), "v"(d[10]), "v"(d[11]), "v"(d[12]), "v"(d[13]), "v"(d[14]), "v"(d[15]));
+    return (c0 + c1) + (c2 + c3);
+}
+
+template <bool ON>
+struct DenseOps {};
+template <>
+struct DenseOps<true> {
+    float D2[16], D4[16];  // M_h^2 and M_h^4: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
+};
+
+// ---------------------------------------------------------------------------------------------
 // packed pairs: the element-wise part of every site step runs on 2-vectors so that the f32
 // instantiation issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one issue slot, two states).
 // A wave can issue one VALU instruction every 4 cycles; at the <= 2 waves per SIMD this problem
@@ -174,7 +229,7 @@ __device__ __forceinline__ vec2<real> splat(real x) {
 // per-lane slice of one sequence's parameters + the forward / backward site steps
 // ---------------------------------------------------------------------------------------------
 template <typename real, int K, int R>
-struct Lane {
+struct Lane : DenseOps<has_dense<real, K, R>()> {
     static constexpr int SPL = K / R;        // states owned by this lane
     static constexpr int NP = (SPL + 1) / 2;  // packed pairs (odd SPL: the last pair's .y is padding)
     static constexpr int EROW = 2 * NP;       // reals per emission row in the LDS table
@@ -255,6 +310,72 @@ struct Lane {
 #pragma unroll
         for (int h = 1; h < NP; ++h) acc = acc + x[h];
         return g.sum(acc[0] + acc[1]);
+    }
+
+    // dense hom operators, forward (row-vector) form: slot j of lane i = (M_h^n)[j][i],
+    // M_h[j][i] = A[j][i] emis0[i],  A[j][i] = b[i] (j > i), d[i] (j == i), u[j] v[i] (j < i).
+    // Built in float64 and rounded once: the same operator is applied L/4 times, so an error in
+    // it acts like a perturbation of the parameters (coherent over the sequence), not like round-off.
+    __device__ __forceinline__ void build_dense_fwd(int rank) {
+        if constexpr (has_dense<real, K, R>()) {
+            double M[16];
+            build_row<0>(M, rank, (double)b[0][0], (double)d[0][0], (double)u[0][0], (double)v[0][0], (double)etab[0]);
+            finish_dense(M);
+        }
+    }
+    // ... beta-scan (column-vector) form: slot j of lane i = (M_h^n)[i][j],
+    // M_h[i][j] = A[i][j] emis0[j],  A[i][j] = b[j] (i > j), d[j] (i == j), u[i] v[j] (i < j)
+    __device__ __forceinline__ void build_dense_bwd(int rank) {
+        if constexpr (has_dense<real, K, R>()) {
+            double M[16];
+            build_col<0>(M, rank, (double)b[0][0], (double)d[0][0], (double)u[0][0], (double)v[0][0], (double)etab[0]);
+            finish_dense(M);
+        }
+    }
+    template <int J>
+    static __device__ __forceinline__ void build_row(double (&M)[16], int rank, double bi, double di, double ui, double vi, double e0) {
+        if constexpr (J < 16) {
+            const double uj = dpp_<0x150 + J>(ui);  // row_share: lane J of this row
+            M[J] = (J > rank ? bi : (J == rank ? di : uj * vi)) * e0;
+            build_row<J + 1>(M, rank, bi, di, ui, vi, e0);
+        }
+    }
+    template <int J>
+    static __device__ __forceinline__ void build_col(double (&M)[16], int rank, double bi, double di, double ui, double vi, double e0) {
+        if constexpr (J < 16) {
+            const double bj = dpp_<0x150 + J>(bi), dj = dpp_<0x150 + J>(di), vj = dpp_<0x150 + J>(vi), ej = dpp_<0x150 + J>(e0);
+            M[J] = (rank > J ? bj : (rank == J ? dj : ui * vj)) * ej;
+            build_col<J + 1>(M, rank, bi, di, ui, vi, e0);
+        }
+    }
+    template <int J>
+    static __device__ __forceinline__ double dot_share(double x, const double (&m)[16]) {
+        if constexpr (J == 16) return 0.0;
+        else return __builtin_fma(dpp_<0x150 + J>(x), m[J], dot_share<J + 1>(x, m));
+    }
+    // D2 = M M, D4 = D2 D2 (both forms: slot j of a product is the dense step applied to slot j of
+    // the left factor read as a vector spread over the lanes of the row)
+    __device__ __forceinline__ void finish_dense(const double (&M)[16]) {
+        if constexpr (has_dense<real, K, R>()) {
+            double P2[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) P2[j] = dot_share<0>(M[j], M);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                this->D2[j] = (float)P2[j];
+                this->D4[j] = (float)dot_share<0>(P2[j], P2);
+            }
+        }
+    }
+
+    // power-of-two rescale of a state vector on its own (the SCALE part of fwd_site / bt_site)
+    __device__ __forceinline__ int rescale(V (&x)[NP]) const {
+        const real c = total(x);
+        const int ex = frexp_exp_(c);
+        const V s2 = splat<real>(ldexp_(real(1), -ex));
+#pragma unroll
+        for (int h = 0; h < NP; ++h) x[h] = x[h] * s2;
+        return ex;
     }
 
     // One forward site (hmm.py:74-79): a <- (a A) .* e_code, then, if SCALE, a *= 2^-ex with ex the
@@ -469,6 +590,8 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     V a[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
+    constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
+    if constexpr (DENSE) lane.build_dense_fwd(rank);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
 
     int E = 0;
@@ -500,7 +623,38 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         }
         const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+        if (DENSE && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+            // full block in the latency-bound layout: groups of 4 sites, one rescale per group (the
+            // NRM = 4 schedule).  All four sequences of the wave hom over the group: one dense
+            // M_h^4 step; else per pair of sites M_h^2 or two structured steps.
+            if constexpr (DENSE) {
+#pragma unroll
+                for (int g = 0; g < T / 4; ++g) {
+                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                    if (__all(c4 == 0u)) {
+                        a[0][0] = dense16(a[0][0], lane.D4);
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                            if (__all(c2 == 0u)) {
+                                a[0][0] = dense16(a[0][0], lane.D2);
+                            } else {
+                                real sc;
+                                V e[NP];
+                                lane.emis(c2 & 3, e);
+                                lane.fwd_site(a, e, sc, false);
+                                lane.emis(c2 >> 2, e);
+                                lane.fwd_site(a, e, sc, false);
+                            }
+                        }
+                    }
+                    const int ex = lane.rescale(a);
+                    E += ex;
+                    ex_min = ex < ex_min ? ex : ex_min;
+                }
+            }
+        } else if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
             // the scheduler can lift every emission ds_read to the top and overlap sites
             V ec[NP];
@@ -594,7 +748,6 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
 
     V beta[NP], gb[NP], gd[NP], gu[NP], gv[NP], g0[NP], g1[NP];
     const real inv_end = (real)A.aux[seq].inv_end;
-    const real inv_w = (real)A.aux[seq].inv_w;
     const int64_t nblk = (A.Ltot + T - 1) / T;
     // block range [blk_lo, blk_hi) of this unit
     int64_t blk_lo = 0, blk_hi = nblk;
@@ -620,6 +773,19 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
             const real f = ldexp_(inv_end, ex);
 #pragma unroll
             for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? src[i < SPL ? i : 0] * f : real(0);
+            // b* (beta scan) and alpha (forward kernel) come from two differently rounded recursions,
+            // so sum_i alpha_t[i] beta_t[i] is 1 only up to their accumulated round-off -- a global
+            // factor on beta that does not decay along the sweep and shows up undamped in d ll/d pi
+            // after the warm-up correction.  Normalise the seed against the forward kernel's own
+            // alpha at this edge (its checkpoint): the identity then holds exactly where the sweep starts.
+            const real* ca = ck + (blk_hi * nseq + seq) * K + rank * SPL;
+            real dot = real(0);
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) dot = fma_(ca[i], L::get(beta, i), dot);
+            dot = lane.g.sum(dot);
+            const V inv = splat<real>(dot > real(0) ? real(1) / dot : real(1));
+#pragma unroll
+            for (int h = 0; h < NP; ++h) beta[h] = beta[h] * inv;
         }
     }
     constexpr bool F64ACC = sizeof(real) == 4 || SEG;  // fold partial sums into the f64 buffer
@@ -726,8 +892,25 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
             for (int i = T - 1; i >= 0; --i) {
                 if (i < ns) {
                     if (t0 + i + 1 == A.W) {
+                        // warm-up boundary: ll = log P(o_1..L) - log P(o_1..W); al[i+1] is alpha_W in
+                        // this kernel's own scaling, beta = d log P(o_1..L) / d alpha_W, and the second
+                        // term contributes -1 / sum(alpha_W).  In exact arithmetic sum_i alpha_W beta = 1,
+                        // so the difference has no component along the direction that survives the
+                        // remaining W sites; in floating point beta carries a global factor 1 + eps
+                        // (round-off of L - W steps) whose image does NOT decay and would dominate
+                        // d ll / d pi.  Dividing beta by the measured sum restores the identity.
+                        V prod[NP];
 #pragma unroll
-                        for (int h = 0; h < NP; ++h) beta[h] = beta[h] - splat<real>(inv_w);
+                        for (int h = 0; h < NP; ++h) prod[h] = al[i + 1][h] * beta[h];
+                        const real sab = lane.total(prod), sa = lane.total(al[i + 1]);
+                        const V is = splat<real>(sab > real(0) ? real(1) / sab : real(1));
+                        const V ic = splat<real>(real(1) / sa);
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) beta[h] = beta[h] * is - ic;
+                        if (A.W == A.Ltot) {  // nothing is scored: the two terms are the same number
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
+                        }
                     }
                     const bool SC = rescale_after<NRM>(i);
                     V e[NP];
@@ -820,6 +1003,8 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     V pi[NP], beta[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
+    constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
+    if constexpr (DENSE) lane.build_dense_bwd(rank);
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? real(1) : real(0);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
@@ -840,7 +1025,34 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
             }
         }
         const int ns = (int)((A.Ltot - w * 16) < 16 ? (A.Ltot - w * 16) : 16);
-        if (ns == 16) {
+        if (DENSE && ns == 16) {
+            // groups of 4 sites, right to left, one rescale per group; dense M_h^4 / M_h^2 steps
+            // where every sequence of the wave is hom over the group (see fwd_kernel)
+            if constexpr (DENSE) {
+#pragma unroll
+                for (int g = 3; g >= 0; --g) {
+                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                    if (__all(c4 == 0u)) {
+                        beta[0][0] = dense16(beta[0][0], lane.D4);
+                    } else {
+#pragma unroll
+                        for (int hh = 1; hh >= 0; --hh) {
+                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                            if (__all(c2 == 0u)) {
+                                beta[0][0] = dense16(beta[0][0], lane.D2);
+                            } else {
+                                V e[NP];
+                                lane.emis(c2 >> 2, e);
+                                lane.bt_site(beta, e, false);
+                                lane.emis(c2 & 3, e);
+                                lane.bt_site(beta, e, false);
+                            }
+                        }
+                    }
+                    F += lane.rescale(beta);
+                }
+            }
+        } else if (ns == 16) {
             V ec[NP];
             lane.emis(codes >> 30, ec);
 #pragma unroll
