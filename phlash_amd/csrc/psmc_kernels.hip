@@ -597,33 +597,59 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
     double llW = 0.0, invW = 0.0;
-    const int64_t nblk = (A.Ltot + T - 1) / T;
-    real* ck = (real*)A.ckpt;
-    // observation words are requested one word (16 sites) ahead: a load issued at the top of the
-    // block that consumes it would expose a full L2 round trip every T sites
-    const int64_t nwords = (A.Ltot + 15) >> 4;
-    uint32_t wcur = 0, wnext = nwords > 0 ? words[0] : 0u;
-    for (int64_t blk = 0; blk < nblk; ++blk) {
-        const int64_t t0 = blk * T;
-        if ((t0 & 15) == 0) {
-            wcur = wnext;
-            const int64_t nx = (t0 >> 4) + 1;
-            wnext = words[nx < nwords ? nx : nwords - 1];
-        }
+    // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
+    // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
+    // an integer division per block (the segment test used to be blk % seg_blocks) cost as much.
+    const int nblk = (int)((A.Ltot + T - 1) / T);
+    const int nfull = (int)(A.Ltot / T);                      // blocks [0, nfull) hold T sites
+    const int tail = (int)(A.Ltot - (int64_t)nfull * T);      // sites of the last, partial block
+    const int blkW = A.W > 0 ? (int)((A.W - 1) / T) : -1;     // block holding the warm-up boundary
+    const int iW = A.W > 0 ? (int)((A.W - 1) - (int64_t)blkW * T) : -1;  // ... after its site iW
+    const int64_t ck_step = nseq * K;
+    real* ckp = (real*)A.ckpt + seq * K + rank * SPL;   // this lane's slice of the current block's checkpoint
+    int16_t* ebp = A.eblk + seq;
+    int32_t* esp = A.eseg + seq;
+    int seg_left = 0;  // blocks until the next segment starts
+    // Observation words come in 16-byte pieces (4 words = 64 sites; rows are padded to whole
+    // pieces), requested one piece ahead, and the block loop is nested inside the piece loop.  The
+    // wait for a piece also waits for every store issued before it completes (vmcnt counts stores,
+    // and the checkpoint stores sit in branches the compiler cannot count through): with the
+    // prefetched word carried around a flat block loop that was a full store round trip per block.
+    constexpr int BPC = 64 / T;  // blocks per piece
+    const uint4* pieces = (const uint4*)words;
+    const int npieces = (int)(A.Lw >> 2);
+    uint4 pnext = pieces[0];
+    int blk = 0;
+    for (int pc = 0; blk < nblk; ++pc) {
+      const uint4 pcur = pnext;
+      pnext = pieces[pc + 1 < npieces ? pc + 1 : npieces - 1];
+      const int bend = blk + BPC < nblk ? blk + BPC : nblk;
+      for (int bi = 0; blk < bend; ++blk, ++bi) {
+        const int tw = (bi * T) & 15;  // first site of the block inside its word
+        const int wsel = (bi * T) >> 4;
+        const uint32_t wcur = wsel == 0 ? pcur.x : (wsel == 1 ? pcur.y : (wsel == 2 ? pcur.z : pcur.w));
         if constexpr (CKPT) {
             if (active) {
-                real* dst = ck + (blk * nseq + seq) * K + rank * SPL;
 #pragma unroll
-                for (int i = 0; i < SPL; ++i) dst[i] = L::get(a, i);
+                for (int i = 0; i < SPL; ++i) ckp[i] = L::get(a, i);
             }
+            ckp += ck_step;
         }
         const int E0 = E;
         if constexpr (CKPT) {
-            if (active && rank == 0 && A.seg_blocks > 0 && blk % A.seg_blocks == 0) A.eseg[(blk / A.seg_blocks) * nseq + seq] = E;
+            if (A.seg_blocks > 0) {
+                if (seg_left == 0) {
+                    if (active && rank == 0) *esp = E;
+                    esp += nseq;
+                    seg_left = A.seg_blocks;
+                }
+                --seg_left;
+            }
         }
-        const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
-        const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        if (DENSE && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+        const uint32_t codes = wcur >> (2 * tw);
+        const bool full = blk < nfull && blk != blkW;  // T sites, no warm-up boundary inside
+        const int ns = blk < nfull ? T : tail;
+        if (DENSE && full) {
             // full block in the latency-bound layout: groups of 4 sites, one rescale per group (the
             // NRM = 4 schedule).  All four sequences of the wave hom over the group: one dense
             // M_h^4 step; else per pair of sites M_h^2 or two structured steps.
@@ -654,7 +680,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                     ex_min = ex < ex_min ? ex : ex_min;
                 }
             }
-        } else if (ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+        } else if (full) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
             // the scheduler can lift every emission ds_read to the top and overlap sites
             V ec[NP];
@@ -683,7 +709,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                     const int ex = lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
                     E += ex;
                     if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
-                    if (t0 + i + 1 == A.W) {
+                    if (blk == blkW && i == iW) {
                         const double cW = (double)lane.total(a);
                         llW = log(cW) + (double)E * LN2;
                         invW = 1.0 / cW;
@@ -692,8 +718,10 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
             }
         }
         if constexpr (CKPT) {
-            if (active && rank == 0) A.eblk[blk * nseq + seq] = (int16_t)(E - E0);
+            if (active && rank == 0) *ebp = (int16_t)(E - E0);
+            ebp += nseq;
         }
+      }
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
@@ -1009,22 +1037,35 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? real(1) : real(0);
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
     int F = 0;
-    const int64_t nw = (A.Ltot + 15) / 16;
-    uint32_t wnext = nw > 0 ? words[nw - 1] : 0u;  // one word ahead of its use
-    for (int64_t w = nw - 1; w >= 0; --w) {
-        const uint32_t codes = wnext;
-        wnext = words[w > 0 ? w - 1 : 0];
-        const int64_t t_hi = (w + 1) * 16;  // first site to the right of this word
-        if (t_hi < A.Ltot && t_hi % seg_sites == 0) {
-            const int64_t sb = t_hi / seg_sites;
+    // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
+    const int nw = (int)((A.Ltot + 15) / 16);
+    const int seg_words = (int)(seg_sites >> 4);  // segments are whole words (SEG_SITES = 512)
+    const int tail = (int)(A.Ltot - (int64_t)(nw - 1) * 16);  // sites in the last word (1..16)
+    // the first segment start met from the right: the largest multiple of seg_sites below Ltot
+    int sb = (int)((A.Ltot - 1) / seg_sites);            // its segment index (0: none to store)
+    int w_store = sb * seg_words - 1;                    // store before processing this word ...
+    // 16-byte pieces (4 words) requested one piece ahead; word loop nested in the piece loop (see fwd_kernel)
+    const uint4* pieces = (const uint4*)words;
+    int w = nw - 1;
+    int pc = w >> 2;
+    uint4 pnext = pieces[pc > 0 ? pc : 0];
+    for (; w >= 0; --pc) {
+      const uint4 pcur = pnext;
+      pnext = pieces[pc > 0 ? pc - 1 : 0];
+      for (const int wlo = pc * 4; w >= wlo; --w) {
+        const int wsel = w & 3;
+        const uint32_t codes = wsel == 0 ? pcur.x : (wsel == 1 ? pcur.y : (wsel == 2 ? pcur.z : pcur.w));
+        if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
             if (active) {
-                real* dst = (real*)bseg_out + (sb * nseq + seq) * K + rank * SPL;
+                real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
 #pragma unroll
                 for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
-                if (rank == 0) fseg_out[sb * nseq + seq] = F;
+                if (rank == 0) fseg_out[(int64_t)sb * nseq + seq] = F;
             }
+            --sb;
+            w_store -= seg_words;
         }
-        const int ns = (int)((A.Ltot - w * 16) < 16 ? (A.Ltot - w * 16) : 16);
+        const int ns = w == nw - 1 ? tail : 16;
         if (DENSE && ns == 16) {
             // groups of 4 sites, right to left, one rescale per group; dense M_h^4 / M_h^2 steps
             // where every sequence of the wave is hom over the group (see fwd_kernel)
@@ -1076,6 +1117,7 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
                 }
             }
         }
+      }
     }
 }
 
