@@ -362,45 +362,68 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     const int64_t units = n_units(h, 8, proto.W);
     if (want_grad && h->L >= 4 * TUNE_SITES && units >= 8 && nseq * best.R / 64 < 1024) {
         const float serial_full = best_ms * (float)h->L / (float)tune_sites;
-        // the beta scan does not depend on T: fastest R2 on the truncated problem
-        int R2 = 0;
-        float b2 = 0.f;
-        for (int R = 1; R <= 16; R <<= 1) {
-            if (!valid_R(K, R)) continue;
-            float ms = 0.f;
-            if ((rc = time_launch([&] { return l.bscan(R, h->nrm, at, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, 256, st); }, &ms)) != PHK_OK) return rc;
-            if (!R2 || ms < b2) { b2 = ms; R2 = R; }
-        }
+        // The forward kernel and the beta scan run concurrently and share the SIMDs: two variants
+        // that are each the fastest alone (e.g. 625 + 625 one-state-per-lane waves on 1,024 SIMDs) can
+        // be slower together than two variants with fewer waves.  So: rank the variants of each kernel
+        // alone on the truncated problem, keep the two fastest of each, and time the whole plan at
+        // full length for every pair (the segment sweep is throughput-bound and its parallelism
+        // depends on L, so it is timed at full length as well).
+        auto two_fastest = [&](auto&& launch_R, int T, int (&out)[2]) -> int {
+            float t[2] = {0.f, 0.f};
+            out[0] = out[1] = 0;
+            for (int R = 1; R <= 16; R <<= 1) {
+                if (!valid_R(K, R) || (T && !valid_T(K, R, T))) continue;
+                float ms = 0.f;
+                int r = time_launch([&] { return launch_R(R); }, &ms);
+                if (r != PHK_OK) return r;
+                if (!out[0] || ms < t[0]) {
+                    out[1] = out[0]; t[1] = t[0];
+                    out[0] = R; t[0] = ms;
+                } else if (!out[1] || ms < t[1]) {
+                    out[1] = R; t[1] = ms;
+                }
+            }
+            return PHK_OK;
+        };
+        int R2s[2];
+        if ((rc = two_fastest([&](int R) { return l.bscan(R, h->nrm, at, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, 256, st); }, 0, R2s)) != PHK_OK) return rc;
         float seg_best = 0.f;
         Plan seg_plan;
         for (int T = 8; T <= 16; T += 8) {
-            // latency-bound forward kernel: fastest R1 for this T on the truncated problem
-            int R1 = 0;
-            float b1 = 0.f;
+            int R1s[2];
             at.seg_blocks = seg_blocks(T);
-            for (int R = 1; R <= 16; R <<= 1) {
-                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
-                float ms = 0.f;
-                if ((rc = time_launch([&] { return l.fwd(R, T, h->nrm, true, at, 256, st); }, &ms)) != PHK_OK) return rc;
-                if (!R1 || ms < b1) { b1 = ms; R1 = R; }
-            }
-            if (!R1) continue;
-            // the segment sweep is throughput-bound and its parallelism depends on L: time the whole
-            // plan at full length for every sweep variant
+            if ((rc = two_fastest([&](int R) { return l.fwd(R, T, h->nrm, true, at, 256, st); }, T, R1s)) != PHK_OK) return rc;
+            if (!R1s[0] || !R2s[0]) continue;
+            // sweep variant with the individually fastest pair, then the pairs with that sweep variant
+            Plan tbest;
+            float tbest_ms = 0.f;
             for (int R = 1; R <= 8; R <<= 1) {
                 if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
                 Plan cand;
                 cand.segmented = 1;
                 cand.T = T;
                 cand.R = R;
-                cand.R1 = R1;
-                cand.R2 = R2;
+                cand.R1 = R1s[0];
+                cand.R2 = R2s[0];
                 float seg_ms = 0.f;
                 if ((rc = timed(a, cand, true, &seg_ms)) != PHK_OK) return rc;
-                if (seg_best == 0.f || seg_ms < seg_best) {
-                    seg_best = seg_ms;
-                    seg_plan = cand;
+                if (tbest_ms == 0.f || seg_ms < tbest_ms) { tbest_ms = seg_ms; tbest = cand; }
+            }
+            if (tbest_ms == 0.f) continue;
+            for (int i1 = 0; i1 < 2; ++i1) {
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    if ((i1 == 0 && i2 == 0) || !R1s[i1] || !R2s[i2]) continue;
+                    Plan cand = tbest;
+                    cand.R1 = R1s[i1];
+                    cand.R2 = R2s[i2];
+                    float seg_ms = 0.f;
+                    if ((rc = timed(a, cand, true, &seg_ms)) != PHK_OK) return rc;
+                    if (seg_ms < tbest_ms) { tbest_ms = seg_ms; tbest = cand; }
                 }
+            }
+            if (seg_best == 0.f || tbest_ms < seg_best) {
+                seg_best = tbest_ms;
+                seg_plan = tbest;
             }
         }
         if (seg_best > 0.f && seg_best < serial_full) best = seg_plan;
