@@ -408,3 +408,76 @@ def test_random_shapes_against_the_oracle(seed):
         assert (np.abs(g - g_ref) / scale).max() < 5e-3
     ll_only = _run(eng, P, inds, W, grad=False)
     np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
+
+
+def _runs_data(rng, n, L, het=0.02, miss_runs=3):
+    """Long hom runs, isolated hets, runs of missing sites: what the dense hom-run operators of the
+    one-state-per-lane kernels (K = 16, float32; psmc_kernels.hip, dense16) are built for."""
+    data = (rng.uniform(size=(n, L)) < het).astype(np.int8)
+    for r in range(n):
+        for _ in range(miss_runs):
+            s = int(rng.integers(0, L))
+            data[r, s:s + int(rng.integers(1, 40))] = -1
+    data[:, 0] = 0
+    return data
+
+
+@pytest.mark.parametrize("T", [8, 16])
+def test_dense_hom_run_operators_f32(T, rng):
+    """K = 16, R = 16, float32, rescale interval 4: the forward kernel and the beta scan take M_h^4 /
+    M_h^2 steps wherever all four sequences of a wave are hom over the group.  Mixed waves (one
+    sequence all hom, one with hets, one with missing runs), ragged length, warm-up boundaries inside
+    and outside dense groups, against the float64 oracle; and the same rows with per-site
+    rescaling (structured steps only) as a second opinion."""
+    L = 4107
+    data = _runs_data(rng, 6, L)
+    data[1] = 0  # an all-hom row: its wave-mates decide whether the dense step is taken
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    P = _params(16, 3, 1, seed=12)
+    inds = np.array([0, 1, 2, 3, 4, 5, 1])
+    # the oracle is fed the float32-rounded parameter block: on the all-hom row |ll| is ~5 and the
+    # rounding of the INPUTS alone moves it by 2e-5 relative -- in every float32 kernel, the
+    # reference's included (scripts/diag_allhom.py) -- which is not what this test is about
+    P32 = P.astype(np.float32).astype(np.float64)
+    for W in (0, 3, 4, 64, 515, L - 700):
+        ll_ref, g_ref = cport.batch(P32, data, inds, W)
+        eng.set_rescale_interval(4)
+        eng.set_variant(16, T)  # serial plan: dense forward kernel, structured backward kernel
+        ll, g = _run(eng, P, inds, W)
+        _check(ll, g, ll_ref, g_ref, False)
+        np.testing.assert_allclose(_run(eng, P, inds, W, grad=False), ll, rtol=1e-6)
+        eng.set_variant(0, 0)
+        eng.set_plan(1, R=4, T=T, R_forward=16, R_scan=16)  # dense forward kernel || dense beta scan
+        ll2, g2 = _run(eng, P, inds, W)
+        _check(ll2, g2, ll_ref, g_ref, False)
+        eng.set_plan(-1)
+        eng.set_rescale_interval(1)  # NRM = 1 instantiations have no dense path
+        eng.set_variant(16, T)
+        ll3, g3 = _run(eng, P, inds, W)
+        np.testing.assert_allclose(ll, ll3, rtol=1e-5, atol=1e-5)  # dense vs structured-only arithmetic
+        eng.set_variant(0, 0)
+
+
+def test_warmup_boundary_keeps_the_pi_row_clean(rng):
+    """With W warm-up sites d ll / d pi is the image, through W steps, of beta_W - 1/sum(alpha_W); any
+    global factor 1 + eps on beta_W (float32 round-off of the L - W steps before it) survives those
+    steps undamped.  The kernels divide beta_W by the measured sum_i alpha_W beta_W (and normalise
+    every segment seed against the forward checkpoint), which keeps the float32 pi row within 5e-2
+    absolute on heterozygous data where it used to be off by > 1."""
+    from phlash_amd.synth import simulate_chunks
+
+    L, W = 20000, 500
+    data = simulate_chunks(16, 6, W + L, seed=int(rng.integers(1 << 30)), theta=0.1)
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    P = _params(16, 3, 1, seed=13, theta=0.1)
+    inds = np.arange(6)
+    ll_ref, g_ref = cport.batch(P, data, inds, W)
+    for plan in ((0, 2, 2, 0), (1, 4, 16, 16), (1, 2, 8, 4)):
+        eng.set_plan(plan[0], R=plan[1], T=8, R_forward=plan[2], R_scan=plan[3])
+        ll, g = _run(eng, P, inds, W)
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-5)
+        assert np.abs(g[..., 6, :] - g_ref[..., 6, :]).max() < 5e-2, plan
+        scale = np.abs(g_ref[..., :6, :]).max(axis=-1, keepdims=True) + 1e-300
+        assert (np.abs(g[..., :6, :] - g_ref[..., :6, :]) / scale).max() < 2e-3, plan
