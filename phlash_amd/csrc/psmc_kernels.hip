@@ -509,7 +509,6 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
 
 struct SeqAux {      // written by the forward kernel, read by the backward kernel
     double inv_end;  // 1 / sum(alpha) after the last site (scaled state)
-    double inv_w;    // 1 / sum(alpha) after the W-th site (0 if W == 0)
     int32_t e_end;   // exponent total E after the last site: true alpha_L = alpha * 2^E
     int32_t pad_;
 };
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
-    double llW = 0.0, invW = 0.0;
+    double llW = 0.0;
     // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
     // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
     // an integer division per block (the segment test used to be blk % seg_blocks) cost as much.
@@ -712,7 +711,6 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                     if (blk == blkW && i == iW) {
                         const double cW = (double)lane.total(a);
                         llW = log(cW) + (double)E * LN2;
-                        invW = 1.0 / cW;
                     }
                 }
             }
@@ -731,7 +729,6 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
         if constexpr (CKPT) {
             A.aux[seq].inv_end = 1.0 / cend;
-            A.aux[seq].inv_w = invW;
             A.aux[seq].e_end = E;
         }
     }
