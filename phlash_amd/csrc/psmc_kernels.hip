@@ -247,7 +247,19 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     const real* etab;  // LDS: this thread's emission rows [3][EROW]: hom, het, missing (= ones)
     Group<real, R> g;
 
-    static __device__ __forceinline__ real get(const V (&x)[NP], int i) { return x[i >> 1][i & 1]; }
+    // Split-halves layout (SPLIT): packed pair h of a lane holds its states h (.x) and h + NP (.y).  The two
+    // running sums of the mat-vec then advance through BOTH halves of the lane's states with one
+    // packed instruction per pair (NP dependent steps instead of SPL scalar ones); the .y half gets
+    // the .x half's total through the same carry add that brings in the other lanes' totals.
+    // Used where it pays (measured at K = 16 on the backward kernel: SPL = 8 -6.5 %; SPL = 16 +2 %, the
+    // instruction count is the same there; SPL = 4 pushes the straight-line path over its register
+    // budget); elsewhere pair h holds the adjacent states 2h, 2h + 1 and the sums run state by state.
+    static constexpr bool SPLIT = SPL == 8;
+    static constexpr int PH(int i) { return SPLIT ? i % NP : i >> 1; }  // pair holding state i of the lane
+    static constexpr int HF(int i) { return SPLIT ? i / NP : i & 1; }   // ... and which half of it
+    static constexpr int SLOT(int i) { return 2 * PH(i) + HF(i); }    // position in an emission-table row
+    static __device__ __forceinline__ real get(const V (&x)[NP], int i) { return x[PH(i)][HF(i)]; }
+    static __device__ __forceinline__ void set(V (&x)[NP], int i, real val) { x[PH(i)][HF(i)] = val; }
 
     // p: [7,K] rows b,d,u,v,emis0,emis1,pi (gpu.py:189 stacking order); padding lanes hold zeros
     // (ones in the emission rows) so that they stay exactly 0 through every step.
@@ -259,16 +271,16 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         for (int h = 0; h < NP; ++h) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int i = 2 * h + c;
+                const int i = SPLIT ? h + c * NP : 2 * h + c;  // state of the lane in half c of pair h
                 const bool ok = i < SPL;
                 b[h][c] = ok ? q[0 * K + i] : real(0);
                 d[h][c] = ok ? q[1 * K + i] : real(0);
                 u[h][c] = ok ? q[2 * K + i] : real(0);
                 v[h][c] = ok ? q[3 * K + i] : real(0);
                 pi[h][c] = ok ? q[6 * K + i] : real(0);
-                etab_thread[0 * EROW + i] = ok ? q[4 * K + i] : real(1);
-                etab_thread[1 * EROW + i] = ok ? q[5 * K + i] : real(1);
-                etab_thread[2 * EROW + i] = real(1);
+                etab_thread[0 * EROW + 2 * h + c] = ok ? q[4 * K + i] : real(1);
+                etab_thread[1 * EROW + 2 * h + c] = ok ? q[5 * K + i] : real(1);
+                etab_thread[2 * EROW + 2 * h + c] = real(1);
             }
         }
     }
@@ -279,27 +291,104 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         for (int h = 0; h < NP; ++h) e[h] = row[h];
     }
 
-    // exclusive prefix of u.*x and exclusive suffix of x over the K states of the sequence
-    __device__ __forceinline__ void scans(const V (&x)[NP], V (&pre_ux)[NP], V (&suf_x)[NP]) const {
-        real tu = real(0);
+    // In-lane part of an exclusive prefix of w.*x (PREFIX) or exclusive suffix (else) over the lane's
+    // states, both halves at once; returns the inclusive totals of the two halves in `tot`.
+    template <bool PREFIX, bool WEIGHTED>
+    __device__ __forceinline__ void half_scans(const V (&w)[NP], const V (&x)[NP], V (&out)[NP], V& tot) const {
+        V t = splat<real>(real(0));
+        if constexpr (PREFIX) {
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                out[h] = t;
+                t = WEIGHTED ? fma2<real>(w[h], x[h], t) : t + x[h];
+            }
+        } else {
+#pragma unroll
+            for (int h = NP - 1; h >= 0; --h) {
+                out[h] = t;
+                t = WEIGHTED ? fma2<real>(w[h], x[h], t) : t + x[h];
+            }
+        }
+        tot = t;
+    }
+    // carry added to every pair: what precedes (PREFIX) / follows the lane's states in other lanes,
+    // plus, for the half that needs it, the total of the lane's other half
+    template <bool PREFIX>
+    __device__ __forceinline__ V carry(const V& tot) const {
+        const real lane_total = SPL > 1 ? tot[0] + tot[1] : tot[0];
+        real c = real(0);
+        if constexpr (R > 1) c = PREFIX ? g.excl_prefix(lane_total) : g.excl_suffix(lane_total);
+        V r;
+        if constexpr (PREFIX) {
+            r[0] = c;
+            r[1] = SPL > 1 ? c + tot[0] : c;  // the .y states also follow every .x state
+        } else {
+            r[0] = SPL > 1 ? c + tot[1] : c;  // the .x states are also followed by every .y state
+            r[1] = c;
+        }
+        return r;
+    }
+    // adjacent-pairs layout: exclusive prefix of wp.*xp into `pre` and exclusive suffix of xs (SUFW:
+    // of v.*xs) into `suf`, state by state inside the lane, then the other lanes' totals
+    __device__ __forceinline__ void serial_scans(const V (&wp)[NP], const V (&xp)[NP], V (&pre)[NP], const V (&xs)[NP],
+                                                 V (&suf)[NP], const bool SUFW) const {
+        real tp = real(0);
 #pragma unroll
         for (int i = 0; i < 2 * NP; ++i) {
-            pre_ux[i >> 1][i & 1] = tu;
-            if (i < SPL) tu = fma_(get(u, i), get(x, i), tu);
+            pre[i >> 1][i & 1] = tp;
+            if (i < SPL) tp = fma_(wp[i >> 1][i & 1], xp[i >> 1][i & 1], tp);
         }
-        real ta = real(0);
+        real ts = real(0);
 #pragma unroll
         for (int i = 2 * NP - 1; i >= 0; --i) {
-            suf_x[i >> 1][i & 1] = ta;
-            if (i < SPL) ta = ta + get(x, i);
+            suf[i >> 1][i & 1] = ts;
+            if (i < SPL) ts = SUFW ? fma_(v[i >> 1][i & 1], xs[i >> 1][i & 1], ts) : ts + xs[i >> 1][i & 1];
         }
         if constexpr (R > 1) {
-            const V cu = splat<real>(g.excl_prefix(tu));
-            const V ca = splat<real>(g.excl_suffix(ta));
+            const V cp = splat<real>(g.excl_prefix(tp));
+            const V cs = splat<real>(g.excl_suffix(ts));
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                pre[h] = pre[h] + cp;
+                suf[h] = suf[h] + cs;
+            }
+        }
+    }
+    // exclusive prefix of u.*x and exclusive suffix of x over the K states of the sequence
+    __device__ __forceinline__ void scans(const V (&x)[NP], V (&pre_ux)[NP], V (&suf_x)[NP]) const {
+        if constexpr (!SPLIT) {
+            serial_scans(u, x, pre_ux, x, suf_x, false);
+            return;
+        }
+        V tu, ta;
+        half_scans<true, true>(u, x, pre_ux, tu);
+        half_scans<false, false>(u, x, suf_x, ta);
+        if constexpr (R > 1 || SPL > 1) {
+            const V cu = carry<true>(tu);
+            const V ca = carry<false>(ta);
 #pragma unroll
             for (int h = 0; h < NP; ++h) {
                 pre_ux[h] = pre_ux[h] + cu;
                 suf_x[h] = suf_x[h] + ca;
+            }
+        }
+    }
+    // exclusive suffix of v.*w and exclusive prefix of b.*w (the adjoint mat-vec)
+    __device__ __forceinline__ void scans_adj(const V (&w)[NP], V (&svw)[NP], V (&pbw)[NP]) const {
+        if constexpr (!SPLIT) {
+            serial_scans(b, w, pbw, w, svw, true);
+            return;
+        }
+        V tv, tb;
+        half_scans<false, true>(v, w, svw, tv);
+        half_scans<true, true>(b, w, pbw, tb);
+        if constexpr (R > 1 || SPL > 1) {
+            const V cv = carry<false>(tv);
+            const V cb = carry<true>(tb);
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                svw[h] = svw[h] + cv;
+                pbw[h] = pbw[h] + cb;
             }
         }
     }
@@ -427,27 +516,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         }
         // suffix of v.*w and prefix of b.*w
         V svw[NP], pbw[NP];
-        real tv = real(0);
-#pragma unroll
-        for (int i = 2 * NP - 1; i >= 0; --i) {
-            svw[i >> 1][i & 1] = tv;
-            if (i < SPL) tv = fma_(get(v, i), get(w, i), tv);
-        }
-        real tb = real(0);
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-            pbw[i >> 1][i & 1] = tb;
-            if (i < SPL) tb = fma_(get(b, i), get(w, i), tb);
-        }
-        if constexpr (R > 1) {
-            const V cv = splat<real>(g.excl_suffix(tv));
-            const V cb = splat<real>(g.excl_prefix(tb));
-#pragma unroll
-            for (int h = 0; h < NP; ++h) {
-                svw[h] = svw[h] + cv;
-                pbw[h] = pbw[h] + cb;
-            }
-        }
+        scans_adj(w, svw, pbw);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             gb[h] = fma2<real>(w[h], suf[h], gb[h]);
@@ -466,27 +535,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         V w[NP], svw[NP], pbw[NP];
 #pragma unroll
         for (int h = 0; h < NP; ++h) w[h] = beta[h] * e[h];
-        real tv = real(0);
-#pragma unroll
-        for (int i = 2 * NP - 1; i >= 0; --i) {
-            svw[i >> 1][i & 1] = tv;
-            if (i < SPL) tv = fma_(get(v, i), get(w, i), tv);
-        }
-        real tb = real(0);
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-            pbw[i >> 1][i & 1] = tb;
-            if (i < SPL) tb = fma_(get(b, i), get(w, i), tb);
-        }
-        if constexpr (R > 1) {
-            const V cv = splat<real>(g.excl_suffix(tv));
-            const V cb = splat<real>(g.excl_prefix(tb));
-#pragma unroll
-            for (int h = 0; h < NP; ++h) {
-                svw[h] = svw[h] + cv;
-                pbw[h] = pbw[h] + cb;
-            }
-        }
+        scans_adj(w, svw, pbw);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             V nb = d[h] * w[h];
@@ -797,7 +846,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
             const int ex = A.fseg[sb * nseq + seq] + A.eseg[sb * nseq + seq] - A.aux[seq].e_end;
             const real f = ldexp_(inv_end, ex);
 #pragma unroll
-            for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? src[i < SPL ? i : 0] * f : real(0);
+            for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) L::set(beta, i, src[i] * f);
             // b* (beta scan) and alpha (forward kernel) come from two differently rounded recursions,
             // so sum_i alpha_t[i] beta_t[i] is 1 only up to their accumulated round-off -- a global
             // factor on beta that does not decay along the sweep and shows up undamped in d ll/d pi
@@ -839,10 +890,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
         real sc[T / NRM];
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            al[0][h][0] = anext[2 * h];
-            al[0][h][1] = (2 * h + 1 < SPL) ? anext[(2 * h + 1 < SPL) ? 2 * h + 1 : 0] : real(0);
-        }
+        for (int h = 0; h < NP; ++h) al[0][h] = splat<real>(real(0));
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) L::set(al[0], i, anext[i]);
         const int e_fwd = A.eblk[blk * nseq + seq];  // exponent total the forward kernel took out of this block
         int e_run = 0;                               // ... and the re-run below
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint under this block's arithmetic
@@ -999,8 +1049,8 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         out[1 * K + i] = (real)(dl ? vd * (double)L::get(lane.d, i) : vd);
         out[2 * K + i] = (real)(dl ? vu * (double)L::get(lane.u, i) : vu);
         out[3 * K + i] = (real)(dl ? vv * (double)L::get(lane.v, i) : vv);
-        out[4 * K + i] = (real)(dl ? v0 : v0 / (double)etab[0 * L::EROW + i]);
-        out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + i]);
+        out[4 * K + i] = (real)(dl ? v0 : v0 / (double)etab[0 * L::EROW + L::SLOT(i)]);
+        out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + L::SLOT(i)]);
         out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)L::get(pi, i) : (double)L::get(beta, i));
     }
 }
@@ -1031,7 +1081,9 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
     if constexpr (DENSE) lane.build_dense_bwd(rank);
 #pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) beta[i >> 1][i & 1] = i < SPL ? real(1) : real(0);
+    for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) L::set(beta, i, real(1));
     const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
     int F = 0;
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
