@@ -481,3 +481,24 @@ def test_warmup_boundary_keeps_the_pi_row_clean(rng):
         assert np.abs(g[..., 6, :] - g_ref[..., 6, :]).max() < 5e-2, plan
         scale = np.abs(g_ref[..., :6, :]).max(axis=-1, keepdims=True) + 1e-300
         assert (np.abs(g[..., :6, :] - g_ref[..., :6, :]) / scale).max() < 2e-3, plan
+
+
+@pytest.mark.parametrize("nrm", [1, 4])
+@pytest.mark.parametrize("R,T", VARIANTS_16)
+def test_k16_f32_variants_tight_on_short_rows(missing_data, R, T, nrm):
+    """The 2e-3 float32 gradient bar is sized for 60,000-site rows; on 1,000-site rows every float32
+    variant sits within 1e-5 of the oracle, so a wrong common factor of 1e-4 on one sequence (seen
+    once in a float64 instantiation whose spill code misbehaved) cannot hide behind it.  Per
+    sequence, W = 0, oracle fed the float32-rounded parameter block."""
+    data = missing_data
+    eng = _engine(16, data, False)
+    eng.set_variant(R, T)
+    eng.set_rescale_interval(nrm)
+    P = _params(16, 3, 1, seed=7)
+    inds = np.arange(len(data))
+    ll, g = _run(eng, P, inds, 0)
+    ll_ref, g_ref = cport.batch(P.astype(np.float32).astype(np.float64), data, inds, 0)
+    np.testing.assert_allclose(ll, ll_ref, rtol=2e-6)
+    scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
+    err = (np.abs(g - g_ref) / scale).max(axis=(-1, -2))  # worst row-scaled error of each sequence
+    assert err.max() < 5e-5, err
