@@ -1079,7 +1079,8 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         out[3 * K + i] = (real)(dl ? vv * (double)L::get(lane.v, i) : vv);
         out[4 * K + i] = (real)(dl ? v0 : v0 / (double)etab[0 * L::EROW + L::SLOT(i)]);
         out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + L::SLOT(i)]);
-        out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)L::get(pi, i) : (double)L::get(beta, i));
+        // pi is re-read here rather than kept in registers through the sweep (the kernel sits at its VGPR budget)
+        out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)prm[6 * K + rank * SPL + i] : (double)L::get(beta, i));
     }
 }
 
