@@ -193,3 +193,38 @@ def test_reference_nograd_kernel_equals_its_grad_kernel():
     ll0 = refcuda.call(16, True, missing, AR, P, grad=False)
     ll1, _, _ = refcuda.call(16, True, missing, AR, P, grad=True)
     np.testing.assert_allclose(ll0, ll1, rtol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 32])
+def test_hip_vs_live_reference_kernels_at_cfg2_row_length(K):
+    """Rows of BASELINE's full length (60,000 scored + 500 leading sites, simulated from the model, 1 %
+    missing) through the reference's float64 gradient kernel, live, next to the HIP kernels in both
+    precisions and two plans.  The reference kernel has no warm-up notion: the rows are scored whole."""
+    import torch
+
+    from phlash_amd.synth import simulate_chunks
+
+    if not refcuda.available(K, True):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    data = simulate_chunks(K, 4, 60_500, seed=77)
+    rng = np.random.default_rng(K)
+    blocks = []
+    for _ in range(2):
+        dm = o.default_dm(f"{K}*1", 1e-2, 1e-2)
+        dm = dm._replace(c=dm.c * np.exp(rng.normal(size=K) * 0.3))
+        blocks.append(o.from_dm(dm).stack())
+    PB = np.repeat(np.stack(blocks)[:, None], 4, axis=1)  # [B, S, 7, K]
+    inds = np.arange(4)
+    ll_r, dlog_r, _ = refcuda.call(K, True, data, inds, PB, grad=True)
+    Pt = torch.tensor(PB, device="cuda")
+    it = torch.tensor(inds, device="cuda")
+    for dbl in (True, False):
+        eng = _engine(K, data, dbl)
+        eng.set_autotune(False)
+        for seg in (0, 1):
+            eng.set_backward_mode(seg)
+            ll_h, dlog_h = eng.run(Pt, it, 0, grad=True, dlog=True)
+            assert eng.get_plan()["segmented"] == seg
+            np.testing.assert_allclose(ll_h.cpu().numpy(), ll_r, rtol=1e-11 if dbl else 1e-5)
+            assert _rowscaled(dlog_h.double().cpu().numpy(), dlog_r) < (1e-8 if dbl else 2e-3), (dbl, seg)
