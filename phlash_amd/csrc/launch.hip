@@ -77,9 +77,13 @@ static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t
         return hipErrorInvalidValue;
     }
 }
+// float64 with 16 states per lane: not compiled (288 VGPRs of state vectors alone; see phk_api.hip, valid_Rb)
+template <int R, int T>
+constexpr bool bwd_variant_ok() { return variant_ok<R, T>() && (sizeof(real_t) == 4 || KK / R <= 8); }
+
 template <int R, int T>
 static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
-    if constexpr (!variant_ok<R, T>()) {
+    if constexpr (!bwd_variant_ok<R, T>()) {
         return hipErrorInvalidValue;
     } else {
         if (nrm == 1) return bwd_rtn<R, T, 1>(a, units, nt, st);

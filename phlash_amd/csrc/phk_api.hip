@@ -158,6 +158,10 @@ bool pick_launchers(const phk_handle* h, Launchers* l) {
 }
 
 bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R <= K && K % R == 0 && K / R <= 16; }
+// The backward kernel keeps T + 1 state vectors of K/R reals per lane in registers.  In float64 with
+// 16 states per lane that is 288 VGPRs for them alone: the instantiation spills 1.6 KB per thread, is
+// never the fastest, and one build of it returned a corrupted gradient element -- it is not compiled.
+bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8); }
 // T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
 bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
 size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
@@ -166,7 +170,7 @@ size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }
 int throughput_R(const phk_handle* h, int64_t units, int T, int waves) {
     int best = 0;
     for (int c = 1; c <= 16; c <<= 1) {
-        if (!valid_R(h->K, c) || !valid_T(h->K, c, T)) continue;
+        if (!valid_Rb(h, c) || !valid_T(h->K, c, T)) continue;
         best = c;
         if (units * c / 64 >= 1024 * (int64_t)waves) break;
     }
@@ -341,7 +345,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         }
         if (want_grad) {
             for (int R = 1; R <= 16; R <<= 1) {
-                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+                if (!valid_Rb(h, R) || !valid_T(K, R, T)) continue;
                 float ms = 0.f;
                 if (!h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
                 if ((rc = time_launch([&] { return l.bwd(R, T, h->nrm, at, 0, 256, st); }, &ms)) != PHK_OK) return rc;
@@ -398,7 +402,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             Plan tbest;
             float tbest_ms = 0.f;
             for (int R = 1; R <= 8; R <<= 1) {
-                if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+                if (!valid_Rb(h, R) || !valid_T(K, R, T)) continue;
                 Plan cand;
                 cand.segmented = 1;
                 cand.T = T;
@@ -542,6 +546,7 @@ int phk_destroy(phk_handle* h) {
 int phk_set_variant(phk_handle* h, int R, int T) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (R != 0 && !valid_R(h->K, R)) return fail(PHK_EINVAL, "R=%d invalid for K=%d", R, h->K);
+    if (R != 0 && !valid_Rb(h, R)) return fail(PHK_EINVAL, "R=%d: the float64 backward kernel needs K/R <= 8 (K=%d)", R, h->K);
     if (T != 0 && T != 8 && T != 16) return fail(PHK_EINVAL, "T must be 0, 8 or 16");
     if (R != 0 && !valid_T(h->K, R, T ? T : 8)) return fail(PHK_EINVAL, "R=%d T=%d not available (T=16 needs K/R <= 4)", R, T);
     h->force_R = R;
@@ -591,7 +596,7 @@ int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int 
     p.T = T;
     p.R1 = R_forward;
     p.R2 = R_scan;
-    if (!valid_R(h->K, p.R) || !valid_T(h->K, p.R, p.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
+    if (!valid_Rb(h, p.R) || !valid_T(h->K, p.R, p.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
     if (p.segmented && (!valid_R(h->K, p.R1) || !valid_R(h->K, p.R2)))
         return fail(PHK_EINVAL, "segmented plan needs valid R_forward and R_scan (got %d, %d)", R_forward, R_scan);
     h->forced_plan = p;
@@ -769,7 +774,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         if (rc != PHK_OK) return rc;
     }
     const Plan plan = choose_plan(h, nseq_launch, W, want_grad ? 1 : 0);
-    if (!valid_R(K, plan.R) || !valid_T(K, plan.R, plan.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
+    if (!(want_grad ? valid_Rb(h, plan.R) : valid_R(K, plan.R)) || !valid_T(K, plan.R, plan.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
     if (plan.segmented && (!valid_R(K, plan.R1) || !valid_R(K, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
     h->last_total = B * S;
     h->last_plan = plan;

@@ -409,18 +409,6 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     }
     // beta_prev = d.*w + pre(b.*w) + u.*suf(v.*w)
     __device__ __forceinline__ V beta_prev(int h, const V (&w)[NP], const V (&svw)[NP], const V (&pbw)[NP], const V& cb) const {
-        // float64 with 16 states per lane is the one instantiation that fails parity in the fused
-        // form (NRM = 1: one sequence in ~30 comes out with every gradient row off by one common
-        // factor of 1e-9..1e-4; every other instantiation agrees with the oracle to 1e-14).  That
-        // kernel sits at 512 VGPRs + 1.6 KB of scratch per thread; its spill code is the suspect, the
-        // arithmetic is the same.  It keeps the unfused form, which passes.
-        if constexpr (sizeof(real) == 8 && SPL >= 16) {
-            V nb = d[h] * w[h];
-            V pb = pbw[h];
-            if constexpr (R > 1 || SPLIT) pb = pb + cb;
-            nb = nb + pb;
-            return fma2<real>(u[h], svw[h], nb);
-        }
         V nb = fma2<real>(d[h], w[h], pbw[h]);
         if constexpr (R > 1 || SPLIT) nb = nb + cb;
         return fma2<real>(u[h], svw[h], nb);

@@ -72,7 +72,14 @@ VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (4, 16), (8, 16), (16, 1
 def test_k16_all_variants(missing_data, R, T, W, nrm, dbl):
     data = missing_data
     eng = _engine(16, data, dbl)
-    eng.set_variant(R, T)
+    if dbl and 16 // R > 8:
+        # the float64 backward kernel is not built for 16 states per lane (phk_api.hip, valid_Rb);
+        # as the forward variant of a plan R = 1 stays available
+        with pytest.raises(AssertionError):
+            eng.set_variant(R, T)
+        eng.set_plan(0, R=2, T=T, R_forward=R, R_scan=0)
+    else:
+        eng.set_variant(R, T)
     eng.set_rescale_interval(nrm)
     B, S = 3, len(data)
     P = _params(16, B, 1, seed=7)
@@ -91,7 +98,10 @@ def test_other_K(K, R, dbl, rng):
     data = (rng.uniform(size=(6, 700)) < 0.08).astype(np.int8)
     data.flat[rng.integers(0, data.size, 40)] = -1
     eng = _engine(K, data, dbl)
-    eng.set_variant(R, 8)
+    if dbl and K // R > 8:
+        eng.set_plan(0, R=2 * R, T=8, R_forward=R, R_scan=0)  # float64: backward kernel needs K/R <= 8
+    else:
+        eng.set_variant(R, 8)
     P = _params(K, 2, 1, seed=3)
     inds = np.array([5, 0, 3, 3])
     for nrm in (1, 2, 4):
@@ -109,7 +119,7 @@ def test_ragged_lengths(L, rng):
     eng = _engine(16, data, True)
     P = _params(16, 2, 1, seed=1)
     inds = np.arange(3)
-    for R, T, nrm in [(1, 8, 1), (4, 8, 4), (16, 16, 2), (2, 8, 4)]:
+    for R, T, nrm in [(2, 8, 1), (4, 8, 4), (16, 16, 2), (8, 8, 2)]:
         eng.set_variant(R, T)
         eng.set_rescale_interval(nrm)
         for W in sorted({0, min(3, L), L}):
@@ -381,7 +391,7 @@ def test_random_shapes_against_the_oracle(seed):
     eng = _engine(K, data, dbl)
     eng.set_rescale_interval(int(rng.choice([1, 2, 4])))
     mode = int(rng.integers(4))
-    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= 16]
+    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]
     if mode == 0:
         R = int(rng.choice(Rs))
         eng.set_variant(R, 16 if (K // R <= 4 and rng.integers(2)) else 8)
