@@ -512,3 +512,24 @@ def test_k16_f32_variants_tight_on_short_rows(missing_data, R, T, nrm):
     scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
     err = (np.abs(g - g_ref) / scale).max(axis=(-1, -2))  # worst row-scaled error of each sequence
     assert err.max() < 5e-5, err
+
+
+@pytest.mark.parametrize("K,R", [(32, 2), (32, 4), (32, 8), (32, 16), (64, 4), (64, 8), (64, 16), (8, 1), (8, 8), (4, 2)])
+def test_other_K_f32_variants_tight_on_short_rows(K, R, rng):
+    """Same per-sequence 5e-5 bound for the other state counts (every backward instantiation that
+    spills or sits at its register budget is in this list)."""
+    data = (rng.uniform(size=(9, 800)) < 0.06).astype(np.int8)
+    data.flat[rng.integers(0, data.size, 60)] = -1
+    data[:, 0] = 0
+    eng = _engine(K, data, False)
+    P = _params(K, 2, 1, seed=21)
+    inds = np.arange(9)
+    ll_ref, g_ref = cport.batch(P.astype(np.float32).astype(np.float64), data, inds, 0)
+    scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
+    for nrm in (1, 4):
+        eng.set_variant(R, 8)
+        eng.set_rescale_interval(nrm)
+        ll, g = _run(eng, P, inds, 0)
+        np.testing.assert_allclose(ll, ll_ref, rtol=2e-6)
+        err = (np.abs(g - g_ref) / scale).max(axis=(-1, -2))
+        assert err.max() < 5e-5, (nrm, err)
