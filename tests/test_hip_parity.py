@@ -533,3 +533,20 @@ def test_other_K_f32_variants_tight_on_short_rows(K, R, rng):
         np.testing.assert_allclose(ll, ll_ref, rtol=2e-6)
         err = (np.abs(g - g_ref) / scale).max(axis=(-1, -2))
         assert err.max() < 5e-5, (nrm, err)
+
+
+@pytest.mark.parametrize("plan", [(1, 4, 16, 16), (1, 4, 8, 16), (1, 4, 16, 8), (1, 2, 4, 4), (1, 16, 16, 16), (0, 2, 16, 0), (0, 16, 1, 0)])
+def test_every_plan_as_first_call_on_a_fresh_engine(plan, rng):
+    """Scratch buffers of a fresh kernel object are uninitialised: a kernel of a plan that failed to
+    write what the next one reads would be masked by the leftovers of an earlier plan on the same
+    object.  Here each plan is the first gradient call of its own object."""
+    data = _runs_data(rng, 5, 2300)
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    eng.set_plan(plan[0], R=plan[1], T=8, R_forward=plan[2], R_scan=plan[3])
+    P = _params(16, 2, 1, seed=14)
+    inds = np.arange(5)
+    ll, g = _run(eng, P, inds, 100)
+    ll_ref, g_ref = cport.batch(P.astype(np.float32).astype(np.float64), data, inds, 100)
+    _check(ll, g, ll_ref, g_ref, False)
+    assert np.isfinite(g).all()
