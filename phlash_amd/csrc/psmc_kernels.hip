@@ -683,6 +683,13 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     const uint4* pieces = (const uint4*)words;
     const int npieces = (int)(A.Lw >> 2);
     uint4 pnext = pieces[0];
+    // land the first piece before the loop (an empty asm that reads it): otherwise "the register of
+    // the current piece may still be in flight" is a state the compiler carries around the block loop,
+    // and it waits (vmcnt) before every block's word select -- which also drains that block's
+    // checkpoint stores.  float32 kernels only: the float64 K = 64 forward kernel (pieces and
+    // parameters loaded straight into AGPRs, scratch in use) returned wrong log-likelihoods with it,
+    // in this form and with an explicit s_waitcnt alike, and passes without.
+    if constexpr (sizeof(real) == 4) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));
     int blk = 0;
     for (int pc = 0; blk < nblk; ++pc) {
       const uint4 pcur = pnext;
@@ -1115,6 +1122,7 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     int w = nw - 1;
     int pc = w >> 2;
     uint4 pnext = pieces[pc > 0 ? pc : 0];
+    if constexpr (sizeof(real) == 4) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
     for (; w >= 0; --pc) {
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];
