@@ -1,10 +1,13 @@
 """Generates tests/golden/psmc_golden.npz from the float64 oracle (numpy loops).
 
-RESTATEMENT-DERIVED, NOT REFERENCE-CAPTURED: the reference cannot be run in this environment (no
-jax, no CUDA; see oracle/__init__.py), so these vectors freeze the oracle's own output on the
+RESTATEMENT-DERIVED, NOT REFERENCE-CAPTURED: the reference's Python cannot be run in this
+environment (no jax; see oracle/__init__.py), so these vectors freeze the oracle's own output on the
 reference's test inputs (tests/conftest.py:14-36: seeds 0/1/2, Bernoulli(0.05) 10 x 1000 int8,
 DemographicModel.default("16*1", theta=1e-2, rho=1e-2); tests/test_gpu.py:16-20: 1 % missing).
-They guard against regressions of the oracle and give the HIP tests a fixed target.
+They guard against regressions of the oracle and give the HIP tests a fixed target.  The
+reference-captured counterpart (outputs of the reference's own kernels, compiled for gfx950) is
+tests/golden/ref_cuda_golden.npz, made by oracle/make_ref_golden.py; where the two files overlap
+(the conftest inputs) they agree to 1e-13 (tests/test_ref_cuda.py).
 
     python -m oracle.make_golden
 """
