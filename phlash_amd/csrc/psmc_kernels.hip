@@ -646,9 +646,22 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     const int64_t nseq = A.B * A.S;
     const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
     const bool active = gid < nseq;
-    const int64_t seq = active ? gid : nseq - 1;
     const int rank = threadIdx.x & (R - 1);
-    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+    // Which sequence a lane group works on is free (sequences are independent; everything stored is
+    // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
+    // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
+    // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
+    // alone would (hom^4 per group instead of hom^16).
+    const int64_t lin = active ? gid : nseq - 1;
+    int64_t bb, ss;
+    if constexpr (has_dense<real, K, R>()) {
+        ss = lin / A.B;
+        bb = lin - ss * A.B;
+    } else {
+        bb = lin / A.S;
+        ss = lin - bb * A.S;
+    }
+    const int64_t seq = bb * A.S + ss;
 
     L lane;
     V a[NP];
@@ -1094,9 +1107,22 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     const int64_t nseq = A.B * A.S;
     const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
     const bool active = gid < nseq;
-    const int64_t seq = active ? gid : nseq - 1;
     const int rank = threadIdx.x & (R - 1);
-    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+    // Which sequence a lane group works on is free (sequences are independent; everything stored is
+    // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
+    // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
+    // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
+    // alone would (hom^4 per group instead of hom^16).
+    const int64_t lin = active ? gid : nseq - 1;
+    int64_t bb, ss;
+    if constexpr (has_dense<real, K, R>()) {
+        ss = lin / A.B;
+        bb = lin - ss * A.B;
+    } else {
+        bb = lin / A.S;
+        ss = lin - bb * A.S;
+    }
+    const int64_t seq = bb * A.S + ss;
 
     L lane;
     V pi[NP], beta[NP];

@@ -60,7 +60,10 @@ def test_cfg2_properties(dbl):
     ll, g = eng.run(P, inds, W, grad=True)
     ll0 = eng.run(P, inds, W, grad=False)
     assert torch.isfinite(ll).all() and torch.isfinite(g).all()
-    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-12 if dbl else 1e-7)
+    # the gradient call and the forward-only call may run different forward variants (the tuner picks
+    # per shape): float32 variants agree to ~1e-3 absolute on these 60,000-site rows -- 2e-7 of the
+    # typical |ll|, but 4e-5 of a row that is nearly all missing (|ll| ~ 20)
+    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-12 if dbl else 1e-6, atol=0 if dbl else 2e-3)
     # bounded oracle sample: 3 particles x 6 chunks at full length
     sub = [0, 7, 11]
     chunks = [0, 123, 250, 333, 498, 499]
