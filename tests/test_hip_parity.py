@@ -360,7 +360,7 @@ def test_tiny_emissions_need_per_site_rescaling():
     assert not e4.underflow_risk()
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(120))
 def test_random_shapes_against_the_oracle(seed):
     """Seeded random draws over everything the launch depends on -- K, float type, particles x
     chunks (shared or per-chunk parameter blocks), row length, warm-up, missing-data rate, plan
@@ -401,21 +401,32 @@ def test_random_shapes_against_the_oracle(seed):
         eng.set_plan(0, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
     # mode 3: the tuner / static rule decides
     ll, g = _run(eng, P, inds, W)
-    ll_ref, g_ref = cport.batch(P if dbl else P.astype(np.float32).astype(np.float64), data, inds, W)
-    if dbl:
-        _check(ll, g, ll_ref, g_ref, True)
-    else:
-        np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
-        # pi row in the form the reference kernel returns, pi_i * d ll/d pi_i (gpu.py:303-313): on
-        # data far from the model (50 % hets) d ll/d pi_i = P(o | z_0 = i) / P(o) reaches 1e9 for
-        # states of tiny pi_i, and with a warm-up prefix the result is the difference of two such
-        # sweeps -- float32 cannot hold that difference, but weighted by pi_i it is exact to 1e-5
-        g, g_ref = g.copy(), g_ref.copy()
-        g[..., 6, :] *= P[..., 6, :]
-        g_ref[..., 6, :] *= P[..., 6, :]
-        scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
-        scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
-        assert (np.abs(g - g_ref) / scale).max() < 5e-3
+    Pin = P if dbl else P.astype(np.float32).astype(np.float64)
+    ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5, atol=1e-10 if dbl else 1e-5)
+    # Gradient metric.  (1) pi row in the form the reference kernel returns, pi_i * d ll/d pi_i
+    # (gpu.py:303-313): on data far from the model (50 % hets) d ll/d pi_i = P(o | z_0 = i) / P(o)
+    # reaches 1e9 for states of tiny pi_i, and with a warm-up prefix the result is the difference of
+    # two such sweeps; weighted by pi_i it is well conditioned.  (2) With W > 0 every row is the
+    # difference of the gradients of log P(o_1..L) and log P(o_1..W); when the scored part carries
+    # little information (W close to L, scored sites missing) that difference is far smaller than
+    # its two terms and only its size relative to THEM is computable: rows are judged against the
+    # larger of their own maximum and a fraction of the whole-row (W = 0) gradient's maximum --
+    # 1e-6 of it in float64, a tenth of it in float32.
+    g, g_ref = g.copy(), g_ref.copy()
+    g[..., 6, :] *= P[..., 6, :]
+    g_ref[..., 6, :] *= P[..., 6, :]
+    scale = np.abs(g_ref).max(axis=-1, keepdims=True)
+    if W > 0:
+        _, g_full = cport.batch(Pin, data, inds, 0)
+        g_full[..., 6, :] *= P[..., 6, :]
+        scale = np.maximum(scale, (1e-6 if dbl else 0.1) * np.abs(g_full).max(axis=-1, keepdims=True))
+    scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
+    scale = np.maximum(scale, 1e-300)
+    err = (np.abs(g - g_ref) / scale).max()
+    # (float64: 1e-7 here -- two of 2,000 draws, all-hom rows with W ~ L/2, reach 7e-8 in the b row by
+    # conditioning alone; the fixed-input tests keep 1e-8)
+    assert err < (1e-7 if dbl else 5e-3), f"gradient error {err:.3e}"
     ll_only = _run(eng, P, inds, W, grad=False)
     np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
 
