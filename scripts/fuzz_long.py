@@ -1,0 +1,55 @@
+"""Dev: random long-row draws (L up to 70,000; plans incl. the tuner; K 16/32; both precisions) against the
+C oracle.  Complements tests/test_hip_parity.py::test_random_shapes_against_the_oracle (L <= 2,600)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from oracle import cport  # noqa: E402
+import test_hip_parity as t  # noqa: E402
+from phlash_amd.synth import simulate_chunks  # noqa: E402
+
+first, last = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+t0 = time.time()
+for seed in range(first, last):
+    rng = np.random.default_rng(50_000 + seed)
+    K = int(rng.choice([16, 16, 16, 32]))
+    dbl = bool(rng.integers(3) == 0)
+    B, S = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+    L = int(rng.choice([3000, 8191, 8192, 20000, 60500, 70001]))
+    W = int(rng.choice([0, 1, 500, 513, 1000]))
+    theta = float(rng.choice([0.003, 0.01, 0.05, 0.1]))
+    data = simulate_chunks(K, S + 2, L, seed=int(rng.integers(1 << 30)), theta=theta)
+    inds = rng.integers(0, S + 2, size=S)
+    P = t._params(K, B, 1, seed=seed, theta=theta)
+    eng = t._engine(K, data, dbl)
+    eng.set_rescale_interval(int(rng.choice([1, 2, 4, 4, 4])))
+    mode = int(rng.integers(4))
+    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]
+    desc = "tuner"
+    if mode == 0:
+        R = int(rng.choice(Rs)); eng.set_variant(R, 8); desc = f"variant R={R}"
+    elif mode == 1:
+        a, b, c = int(rng.choice(Rs)), int(rng.choice(Rs)), int(rng.choice(Rs))
+        eng.set_plan(1, R=a, T=8, R_forward=b, R_scan=c); desc = f"seg R={a} Rf={b} Rs={c}"
+    elif mode == 2:
+        a, b = int(rng.choice(Rs)), int(rng.choice(Rs))
+        eng.set_plan(0, R=a, T=8, R_forward=b, R_scan=0); desc = f"serial R={a} Rf={b}"
+    ll, g = t._run(eng, P, inds, W)
+    Pin = P if dbl else P.astype(np.float32).astype(np.float64)
+    ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+    g = g.copy(); g_ref = g_ref.copy()
+    g[..., 6, :] *= P[..., 6, :]; g_ref[..., 6, :] *= P[..., 6, :]
+    scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
+    scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
+    gerr = (np.abs(g - g_ref) / scale).max()
+    llerr = np.abs(ll / ll_ref - 1).max()
+    ok = np.isfinite(g).all() and llerr < (1e-10 if dbl else 1e-5) and gerr < (1e-7 if dbl else 5e-3)
+    if not ok:
+        bad.append(seed)
+    print(f"{'ok ' if ok else 'BAD'} seed {seed}: K={K} dbl={dbl} B={B} S={S} L={L} W={W} theta={theta} {desc} -> ll {llerr:.1e} grad {gerr:.1e}", flush=True)
+print(f"seeds {first}..{last - 1}: {len(bad)} bad {bad} in {time.time() - t0:.0f} s")
