@@ -47,7 +47,10 @@ for seed in range(first, last):
     scale = np.abs(g_ref).max(axis=-1, keepdims=True) + 1e-300
     scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
     gerr = (np.abs(g - g_ref) / scale).max()
-    llerr = np.abs(ll / ll_ref - 1).max()
+    # float32: 1e-5 relative, or 3e-3 absolute on rows that are nearly all hom (|ll| ~ 5 over 60,000 sites:
+    # the state is stationary there, every step rounds the same way and the bias adds up to ~1e-3 in
+    # every float32 variant and in the reference's float32 kernels alike -- scripts/fuzz_long_triage.py)
+    llerr = np.minimum(np.abs(ll / ll_ref - 1), np.abs(ll - ll_ref) / (1e-300 if dbl else 300.0)).max()
     ok = np.isfinite(g).all() and llerr < (1e-10 if dbl else 1e-5) and gerr < (1e-7 if dbl else 5e-3)
     if not ok:
         bad.append(seed)
