@@ -228,7 +228,9 @@ def main():
                             f"all-reduce, chain rule, SVGD update)",
                 "K": K, "particles": B, "chunks_per_gpu": S, "chunk_size": L, "overlap": W,
                 "kernel_variant": {"lanes_per_sequence": R, "checkpoint_block": T,
-                                   "plan": "segmented" if plan["segmented"] else "serial"},
+                                   "plan": "segmented" if plan["segmented"] else ("hybrid" if plan.get("hybrid_first") else "serial"),
+                                   **({"serial_sequences": plan["hybrid_first"], "segment_sweep_lanes": plan["R_segment_sweep"]}
+                                      if plan.get("hybrid_first") else {})},
                 "sharding": f"chunk rows sharded over {world} rank(s), one all-reduce of [B, 1+7K] f64 per step",
             },
             "kernel_ms_per_step": {"forward": fwd_ms / a.steps, "backward": bwd_ms / a.steps},

@@ -27,7 +27,7 @@ static size_t lds_bytes(int R, int nt) {
 
 template <int R, int T, int NRM>
 static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
-    const int64_t nseq = a.B * a.S;
+    const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
     const int spb = nt / R;  // sequences per workgroup
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
     const size_t lds = lds_bytes(R, nt);
@@ -40,7 +40,7 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
 
 template <int R, int T, int NRM>
 static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
-    const int64_t nseq = a.B * a.S;
+    const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
     const int spb = nt / R;
     const dim3 block(nt);
     if (units <= 0) {  // one serial sweep per sequence
@@ -55,7 +55,7 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
 
 template <int R, int NRM>
 static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
-    const int64_t nseq = a.B * a.S;
+    const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
     const int spb = nt / R;
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
     hipLaunchKernelGGL((bscan_kernel<real_t, KK, R, NRM>), grid, block, lds_bytes(R, nt), st, a, seg_sites, bseg, fseg);
@@ -149,7 +149,7 @@ hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, in
     return hipErrorInvalidValue;
 }
 hipError_t PHK_CAT(launch_finalize_, PHK_SUFFIX)(const KArgs& a, hipStream_t st) {
-    const int64_t n = a.B * a.S * KK;
+    const int64_t n = ((a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin) * KK;
     hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, KK);
     return hipGetLastError();
 }

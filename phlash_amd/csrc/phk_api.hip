@@ -103,6 +103,12 @@ struct Plan {
     int segmented = 0;
     int R = 2, T = 8;    // serial: backward kernel; segmented: R = R3 of the segment sweep
     int R1 = 0, R2 = 0;  // forward kernel (0: same as R) / beta scan (segmented only)
+    // hybrid (serial plan only): sequences [0, hybrid_first) are swept serially by (R, T); the rest is
+    // swept by segments with variant R3 (seeds from a beta scan with R2), concurrently, so that the
+    // many short segment units fill the wave slots the serial sweep leaves empty (at cfg2: 1,563
+    // serial waves on 2,048 slots).  0: no hybrid.
+    int64_t hybrid_first = 0;
+    int R3 = 0;
 };
 
 }  // namespace
@@ -122,7 +128,7 @@ struct phk_handle {
     int64_t last_total = -1;  // B*S of the last phk_loglik and the plan it ran with
     Plan last_plan;
     hipStream_t side = nullptr;  // second stream of the segmented plan
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
     std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch since the last timing query
     int n_launches = 0;          // launches recorded since the last query
@@ -207,6 +213,14 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
 }
 
 Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
+    if (const char* env = std::getenv("PHK_HYBRID")) {  // developer override: "R:Rf:first:R3:R2"
+        Plan p;
+        long long first = 0;
+        if (want_grad && std::sscanf(env, "%d:%d:%lld:%d:%d", &p.R, &p.R1, &first, &p.R3, &p.R2) == 5) {
+            p.hybrid_first = first;
+            return p;
+        }
+    }
     if (h->has_forced_plan) {
         Plan p = h->forced_plan;
         if (!want_grad) {
@@ -258,6 +272,35 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         return PHK_OK;
     }
     if (!h->dbl || plan.segmented) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
+    if (!plan.segmented && plan.hybrid_first > 0 && plan.hybrid_first < nseq && n_units(h, plan.T, a.W) >= 2) {
+        // hybrid: forward kernel over everything || beta scan over the tail range; then the serial
+        // sweep of the head range || the segment sweep + finalize of the tail range
+        phk::KArgs a1 = a, a2 = a;
+        a1.seq_begin = 0;
+        a1.seq_end = plan.hybrid_first;
+        a2.seq_begin = plan.hybrid_first;
+        a2.seq_end = nseq;
+        const int Rf = plan.R1 ? plan.R1 : plan.R;
+        HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));  // (float64 too: the segments add into it)
+        HIP_TRY(hipEventRecord(h->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        e = l.bscan(plan.R2, h->nrm, a2, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
+        if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (hybrid, K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
+        e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, Rf, plan.T, hipGetErrorString(e));
+        if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
+        HIP_TRY(hipEventRecord(h->ev_fwd, st));
+        HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fwd, 0));
+        const int units = (int)n_units(h, plan.T, a.W);
+        e = l.bwd(plan.R3, plan.T, h->nrm, a2, units, nt, h->side);
+        if (e == hipSuccess) e = l.fin(a2, h->side);
+        if (e != hipSuccess) return fail(PHK_EHIP, "segment sweep launch (hybrid, K=%d R=%d T=%d): %s", K, plan.R3, plan.T, hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(h->ev_join, h->side));
+        e = l.bwd(plan.R, plan.T, h->nrm, a1, 0, nt, st);
+        if (e != hipSuccess) return fail(PHK_EHIP, "backward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+        return PHK_OK;
+    }
     if (!plan.segmented) {
         const int Rf = plan.R1 ? plan.R1 : plan.R;
         e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
@@ -360,6 +403,32 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             best.T = T;
             best.R = bb;
             best.R1 = bf;
+        }
+    }
+    // hybrid: the serial sweep runs whole waves of 64/R sequences, two per SIMD at most.  Whatever does
+    // not fill a round of 1,024 waves either leaves wave slots empty for the whole sweep (cfg2: 1,563
+    // waves on 2,048 slots) or runs as a thin extra round.  Give that remainder to the segment sweep,
+    // whose many short units fill whatever slots are free, concurrently with the serial sweep of the rest.
+    if (want_grad && best.T == 8 && h->L >= 4 * TUNE_SITES && n_units(h, 8, proto.W) >= 8 && valid_Rb(h, best.R)) {
+        const int64_t per_round = 1024 * (int64_t)(64 / best.R);
+        const int64_t first = (nseq / per_round) * per_round;
+        if (first > 0 && nseq - first > per_round / 20) {
+            Plan hbest_plan;
+            float hbest = 0.f;
+            const int cand[3][2] = {{4, 2}, {2, 2}, {4, 4}};  // (segment sweep, beta scan) lanes per sequence
+            for (const auto& c : cand) {
+                if (!valid_Rb(h, c[0]) || !valid_T(K, c[0], 8) || !valid_R(K, c[1])) continue;
+                Plan hyb = best;
+                hyb.hybrid_first = first;
+                hyb.R3 = c[0];
+                hyb.R2 = c[1];
+                float ms = 0.f;
+                if ((rc = timed(a, hyb, true, &ms)) != PHK_OK) return rc;
+                if (hbest == 0.f || ms < hbest) { hbest = ms; hbest_plan = hyb; }
+            }
+            float full_ms = 0.f;  // the serial plan at full length, same conditions
+            if ((rc = timed(a, best, true, &full_ms)) != PHK_OK) return rc;
+            if (hbest > 0.f && hbest < full_ms) best = hbest_plan;
         }
     }
     // segmented plan: only worth a look where the serial sweep cannot fill the chip
@@ -490,7 +559,8 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     }
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fwd, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return fail(PHK_EHIP, "could not create the side stream");
     }
@@ -535,6 +605,7 @@ int phk_destroy(phk_handle* h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_fwd) (void)hipEventDestroy(h->ev_fwd);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->tune_ll, &h->tune_grad, &h->risk})
         b->release();
@@ -612,6 +683,16 @@ int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, 
     if (T) *T = p.T;
     if (R_forward) *R_forward = p.R1 ? p.R1 : p.R;
     if (R_scan) *R_scan = p.segmented ? p.R2 : 0;
+    return PHK_OK;
+}
+
+int phk_get_plan_hybrid(phk_handle* h, int64_t* first, int* R_sweep, int* R_scan) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    const Plan& p = h->last_plan;
+    const bool on = !p.segmented && p.hybrid_first > 0;
+    if (first) *first = on ? p.hybrid_first : 0;
+    if (R_sweep) *R_sweep = on ? p.R3 : 0;
+    if (R_scan) *R_scan = on ? p.R2 : 0;
     return PHK_OK;
 }
 
@@ -763,6 +844,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.fseg = (const int32_t*)h->fseg.p;
         a.bpi = (double*)h->bpi.p;
         a.risk = (int*)h->risk.p;
+        a.seq_begin = a.seq_end = 0;
         return a;
     };
 

@@ -603,6 +603,10 @@ struct KArgs {
     const int32_t* fseg;     // [nseg+1, B*S] its exponents
     double* bpi;             // [B*S, K] d ll / d pi (segmented mode; the serial kernel writes grad itself)
     int* risk;               // set to 1 if a rescale ever found the mass below 2^RISK_EXP (see below)
+    // Sub-range [seq_begin, seq_end) of the sequences (storage index b * S + s) this launch covers;
+    // seq_end == 0 means all.  The hybrid plan sweeps one range serially and the other by segments;
+    // every per-sequence array keeps its full B*S layout.
+    int64_t seq_begin, seq_end;
 };
 
 // With rescaling only every NRM-th site the unscaled mass must survive NRM sites.  A rescale that
@@ -644,17 +648,18 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     static_assert(T % NRM == 0, "the rescale schedule must restart with every block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int64_t nseq = A.B * A.S;
-    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
-    const bool active = gid < nseq;
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
+    const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
+    const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
     // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
     // alone would (hom^4 per group instead of hom^16).
-    const int64_t lin = active ? gid : nseq - 1;
+    const int64_t lin = active ? gid : seq_hi - 1;
     int64_t bb, ss;
-    if constexpr (has_dense<real, K, R>()) {
+    if (has_dense<real, K, R>() && A.seq_begin == 0 && seq_hi == nseq) {
         ss = lin / A.B;
         bb = lin - ss * A.B;
     } else {
@@ -842,9 +847,10 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int64_t nseq = A.B * A.S;
-    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + tid / R;
-    const bool active = gid < nseq;
-    const int64_t seq = active ? gid : nseq - 1;
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
+    const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + tid / R;
+    const bool active = gid < seq_hi;
+    const int64_t seq = active ? gid : seq_hi - 1;
     const int rank = tid & (R - 1);
     const int64_t bb = seq / A.S, ss = seq - bb * A.S;
 
@@ -1105,17 +1111,18 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     constexpr int SPL = L::SPL, NP = L::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int64_t nseq = A.B * A.S;
-    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
-    const bool active = gid < nseq;
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
+    const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
+    const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
     // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
     // alone would (hom^4 per group instead of hom^16).
-    const int64_t lin = active ? gid : nseq - 1;
+    const int64_t lin = active ? gid : seq_hi - 1;
     int64_t bb, ss;
-    if constexpr (has_dense<real, K, R>()) {
+    if (has_dense<real, K, R>() && A.seq_begin == 0 && seq_hi == nseq) {
         ss = lin / A.B;
         bb = lin - ss * A.B;
     } else {
@@ -1224,8 +1231,8 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
 // gacc [B*S, 6, K] + bpi [B*S, K] -> grad [B*S, 7, K]   (segmented mode)
 template <typename real>
 __global__ void grad_finalize_kernel(KArgs A, int K) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nseq = A.B * A.S;
+    const int64_t nseq = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+    const int64_t idx = A.seq_begin * K + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nseq * K) return;
     const int64_t seq = idx / K;
     const int k = (int)(idx - seq * K);

@@ -93,7 +93,12 @@ class HipEngine:
     def get_plan(self) -> dict:
         v = [ctypes.c_int() for _ in range(5)]
         _lib.check(_lib.load().phk_get_plan(self._h, *(ctypes.byref(x) for x in v)))
-        return dict(zip(("segmented", "R", "T", "R_forward", "R_scan"), (x.value for x in v)))
+        plan = dict(zip(("segmented", "R", "T", "R_forward", "R_scan"), (x.value for x in v)))
+        first, r3, r2 = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().phk_get_plan_hybrid(self._h, ctypes.byref(first), ctypes.byref(r3), ctypes.byref(r2)))
+        if first.value > 0:  # serial sweep of the first `hybrid_first` sequences || segment sweep of the rest
+            plan.update(hybrid_first=first.value, R_segment_sweep=r3.value, R_scan=r2.value)
+        return plan
 
     def get_variant(self, B: int, S: int) -> tuple[int, int]:
         r, t = ctypes.c_int(), ctypes.c_int()

@@ -78,7 +78,7 @@ def test_cfg2_properties(dbl):
         eng.set_variant(R, 8)
         eng.set_rescale_interval(nrm)
         ll2, g2 = eng.run(P, inds, W, grad=True)
-        np.testing.assert_allclose(ll2.cpu(), ll.cpu(), rtol=1e-11 if dbl else 2e-6)
+        np.testing.assert_allclose(ll2.cpu(), ll.cpu(), rtol=1e-11 if dbl else 2e-6, atol=0 if dbl else 2e-3)  # see above
         gs = g.double().abs().amax(-1, keepdim=True).clamp_min(1.0)
         err = (g2.double() - g.double()).abs() / gs
         # f32: every variant sits ~6e-4 (worst element 2e-3) from the f64 oracle for the same reason -- the

@@ -561,3 +561,34 @@ def test_every_plan_as_first_call_on_a_fresh_engine(plan, rng):
     ll_ref, g_ref = cport.batch(P.astype(np.float32).astype(np.float64), data, inds, 100)
     _check(ll, g, ll_ref, g_ref, False)
     assert np.isfinite(g).all()
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+def test_hybrid_plan_matches_the_oracle(dbl, rng, monkeypatch):
+    """Hybrid form of the serial plan: the first n1 sequences swept serially, the rest by segments,
+    concurrently (the tuner picks it where the serial sweep would leave wave slots empty: cfg2).  Forced
+    here at a small size through the developer override; both ranges against the oracle, with and
+    without a warm-up prefix, and the gradient buffer shared by the two sweeps checked for leaks
+    between calls."""
+    L = 2300
+    data = _runs_data(rng, 5, L, het=0.05)
+    eng = _engine(16, data, dbl)
+    eng.set_autotune(False)
+    P = _params(16, 3, 1, seed=17)
+    inds = np.array([0, 1, 2, 3, 4, 2])  # 18 sequences
+    Pin = P if dbl else P.astype(np.float32).astype(np.float64)
+    for spec, W in (("2:2:7:4:2", 0), ("2:1:7:2:2", 100), ("4:2:16:4:4", 600), ("2:2:1:2:2", 100), ("2:2:17:4:2", 0)):
+        if dbl and spec.startswith("2:1:"):
+            spec = "2:2:" + spec[4:]
+        monkeypatch.setenv("PHK_HYBRID", spec)
+        ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+        for _ in range(2):
+            ll, g = _run(eng, P, inds, W)
+            plan = eng.get_plan()
+            assert plan.get("hybrid_first") == int(spec.split(":")[2]) and plan["segmented"] == 0
+            _check(ll, g, ll_ref, g_ref, dbl)
+        # forward-only calls ignore the hybrid split
+        np.testing.assert_allclose(_run(eng, P, inds, W, grad=False), ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
+    monkeypatch.delenv("PHK_HYBRID")
+    ll, g = _run(eng, P, inds, 0)
+    assert "hybrid_first" not in eng.get_plan()
