@@ -8,8 +8,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-export PHK_AUTOTUNE=0   # profile the static plan only (the tuner would add short runs of every variant)
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+# the tuner runs (a few extra launches of every candidate at the start of each pass)
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
