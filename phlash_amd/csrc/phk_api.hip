@@ -557,7 +557,13 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
         delete h;
         return fail(PHK_ENOMEM, "could not allocate the underflow flag");
     }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+    // The second stream must run concurrently with the caller's: HIP maps streams onto a few hardware
+    // queues in creation order, and two streams that share a queue serialise (seen with RCCL
+    // initialised in the process: the side stream landed on the compute stream's queue and the hybrid /
+    // segmented plans lost their overlap).  Streams of another priority level get queues of their own.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fwd, hipEventDisableTiming) != hipSuccess) {
