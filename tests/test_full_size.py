@@ -145,3 +145,30 @@ def test_cfg4_K64_and_cfg5_K32_shapes():
         assert (np.abs(gg - g_ref) / scale).max() < 2e-3
         if K == 32:
             assert eng.workspace_bytes() < (3 << 30)
+
+
+def test_cfg2_full_batch_hybrid_plan(monkeypatch):
+    """The whole cfg2 batch (100 x 500 x 60,000 + 500 warm-up, float32) under the hybrid plan the tuner
+    picks for it -- forced here so that the test does not depend on a timing: sequences [0, 32768) by
+    the serial sweep, the other 17,232 by segments at the same time.  A sample from both ranges against
+    the oracle, and the serial plan on the same batch."""
+    K, B, S, L, W = 16, 100, 500, 60_000, 500
+    data, P, eng = _setup(K, B, S, L, W, False)
+    eng.set_autotune(False)
+    inds = torch.arange(S, device="cuda")
+    monkeypatch.setenv("PHK_HYBRID", "2:1:32768:4:2")
+    ll, g = eng.run(P, inds, W, grad=True)
+    plan = eng.get_plan()
+    assert plan.get("hybrid_first") == 32768 and plan["R_segment_sweep"] == 4
+    monkeypatch.delenv("PHK_HYBRID")
+    eng.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
+    ll_s, g_s = eng.run(P, inds, W, grad=True)
+    assert torch.isfinite(g).all()
+    np.testing.assert_allclose(ll.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
+    sub, chunks = [0, 40, 65, 66, 99], [0, 267, 268, 499]  # sequence 32768 = particle 65, chunk 268
+    ll_ref, g_ref = cport.batch(P[sub].float().double().cpu().numpy(), data, chunks, W)
+    np.testing.assert_allclose(ll[sub][:, chunks].cpu().numpy(), ll_ref, rtol=1e-5)
+    scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+    for name, gg in (("hybrid", g), ("serial", g_s)):
+        err = (np.abs(gg[sub][:, chunks].double().cpu().numpy() - g_ref) / scale).max()
+        assert err < 2e-3, (name, err)
