@@ -390,8 +390,12 @@ def test_random_shapes_against_the_oracle(seed):
         P = P * np.exp(0.02 * rng.standard_normal(P.shape))
     eng = _engine(K, data, dbl)
     eng.set_rescale_interval(int(rng.choice([1, 2, 4])))
-    mode = int(rng.integers(4))
+    mode = int(rng.integers(5))
     Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]
+    hybrid = None
+    if mode == 4 and B * S >= 2:  # hybrid form of the serial plan with a random split (developer override)
+        Rb = [r for r in Rs if K // r <= 8] if dbl else Rs
+        hybrid = f"{int(rng.choice(Rb))}:{int(rng.choice(Rs))}:{int(rng.integers(1, B * S))}:{int(rng.choice(Rb))}:{int(rng.choice(Rs))}"
     if mode == 0:
         R = int(rng.choice(Rs))
         eng.set_variant(R, 16 if (K // R <= 4 and rng.integers(2)) else 8)
@@ -400,7 +404,14 @@ def test_random_shapes_against_the_oracle(seed):
     elif mode == 2:
         eng.set_plan(0, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
     # mode 3: the tuner / static rule decides
-    ll, g = _run(eng, P, inds, W)
+    import os
+
+    if hybrid:
+        os.environ["PHK_HYBRID"] = hybrid
+    try:
+        ll, g = _run(eng, P, inds, W)
+    finally:
+        os.environ.pop("PHK_HYBRID", None)
     Pin = P if dbl else P.astype(np.float32).astype(np.float64)
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5, atol=1e-10 if dbl else 1e-5)
