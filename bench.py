@@ -10,9 +10,14 @@ backward kernels over all B x S (particle, chunk) sequences -> sum over chunks -
 Work per step = B * S * L scored site.particles per GPU (the W warm-up sites of every chunk are
 run but not counted).
 
-Workload (BASELINE.json configs[1], "cfg2"): 1 diploid, 3 Gb = 500 chunks x 60,000 scored sites
-(+500 warm-up), K = 16, 100 particles, float32 kernels.  Weak scaling: every rank holds its own 500
-chunks (cfg3's layout at N = 8 is 5,000 chunks); the particles are shared.
+Workload (default, BASELINE.json configs[1], "cfg2"): 1 diploid, 3 Gb = 500 chunks x 60,000 scored
+sites (+500 warm-up), K = 16, 100 particles, float32 kernels.  With N > 1 this is WEAK scaling: every
+rank holds its own 500 chunks (4,000 chunks at N = 8); the particles are shared.  ``--config``
+selects the other BASELINE configs (their lines are kept under profiles/, the driver's line is cfg2):
+  cfg3  10 diploids x 3 Gb = 5,000 chunks in all, sharded by chunk rows (625 per rank at N = 8), K = 16,
+        100 particles, AFS term for n = 20 in the step; STRONG scaling (the total is fixed)
+  cfg4  K = 64, 500 chunks, 100 particles            cfg5  K = 32, 500 chunks, 500 particles
+  prod  the reference's production shape: 500 particles x a minibatch of 5 chunks x 100,000 sites
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
 "roofline" (dominant kernel = the backward kernel, timed with HIP events on its launch stream) and
@@ -40,23 +45,48 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 peak (same guide)
 
 
+CONFIGS = {
+    "cfg2": dict(K=16, particles=100, chunks=500, chunk_size=60000, overlap=500, scaling="weak",
+                 what="cfg2 per GPU: 1 diploid, 3 Gb"),
+    "cfg3": dict(K=16, particles=100, chunks=5000, chunk_size=60000, overlap=500, scaling="strong", afs_n=20,
+                 what="cfg3 in all: 10 diploids x 3 Gb, chunk rows sharded over the ranks, AFS term n=20"),
+    "cfg4": dict(K=64, particles=100, chunks=500, chunk_size=60000, overlap=500, scaling="weak",
+                 what="cfg4 per GPU: K=64 fine time grid, 3 Gb"),
+    "cfg5": dict(K=32, particles=500, chunks=500, chunk_size=60000, overlap=500, scaling="weak",
+                 what="cfg5 per GPU: 500 particles, K=32, 3 Gb"),
+    "prod": dict(K=16, particles=500, chunks=5, chunk_size=100000, overlap=500, scaling="weak",
+                 what="reference production shape per GPU: 500 particles x minibatch of 5 chunks (mcmc.py:119-121)"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--K", type=int, default=16)
-    ap.add_argument("--particles", type=int, default=100)
-    ap.add_argument("--chunks", type=int, default=500)
-    ap.add_argument("--chunk-size", type=int, default=60000)
-    ap.add_argument("--overlap", type=int, default=500)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json config (default cfg2)")
+    ap.add_argument("--K", type=int, default=None)
+    ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--chunks", type=int, default=None, help="chunks per GPU (cfg3: in all)")
+    ap.add_argument("--chunk-size", type=int, default=None)
+    ap.add_argument("--overlap", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests that "
+                    "put two ranks on one GPU)")
     ap.add_argument("--double", action="store_true", help="float64 kernels (default float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
     ap.add_argument("--variant", default="", help="R:T override for the kernel variant (dev)")
     ap.add_argument("--nrm", type=int, default=0, help="rescale interval override (dev; 0 = library default)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    for key in ("K", "particles", "chunks", "chunk_size", "overlap"):
+        if getattr(a, key) is None:
+            setattr(a, key, cfg[key])
+    a.strong = cfg["scaling"] == "strong"
+    a.afs_n = cfg.get("afs_n", 0)
+    a.what = cfg["what"]
+    return a
 
 
 def cpu_baseline(P, data, overlap, chunk_size, target_s, ll_gpu):
@@ -117,6 +147,80 @@ def reference_kernel_leg(P, data, overlap, chunk_size, eng, dbl, max_chunks=80):
     }
 
 
+def gradient_parity_leg(template, x0, data, W, dev, kern32, max_ref_chunks=8, max_oracle_particles=4):
+    """The float32 gradient where it is consumed: the [B, D] particle-space gradient of the summed
+    log-likelihood (what SVGD takes), float32 kernels vs float64 kernels on the WHOLE batch, per-particle
+    relative error |g32 - g64| / |g64|.  Next to it, on a bounded sample (all particles x a few chunks,
+    no warm-up: the reference kernel has none), the same figure for the reference's own float32 kernel
+    against its float64 kernel, for ours on that sample, and (a few particles) ours float64 against the
+    CPU oracle.  Outside the timed region; oracle/ and oracle/_ref are used as checkers only."""
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.param_map import particles_to_params
+
+    K = kern32.M
+    xs = x0.to(dev).detach().requires_grad_(True)
+    params = particles_to_params(template, xs)  # [B, 7, K] float64 with its Jacobian
+
+    def to_particle_space(G):  # J^T G, G = d ll_sum / d params [B, 7, K]
+        (gx,) = torch.autograd.grad(params, xs, grad_outputs=G.to(dev), retain_graph=True)
+        return gx
+
+    def rel(ga, gb):
+        r = ((ga - gb).norm(dim=1) / gb.norm(dim=1)).cpu().numpy()
+        return {"max": float(r.max()), "median": float(np.median(r))}
+
+    from phlash_amd.params import PSMCParams
+
+    pp = PSMCParams.unstack(params.detach())
+    S = data.shape[0]
+    inds = torch.arange(S, device=dev)
+    kern64 = get_kernel(K, data, double_precision=True, overlap=W, device=dev.index)
+    _, G32 = kern32.value_and_grad(pp, inds)
+    _, G64 = kern64.value_and_grad(pp, inds)
+    out = {"what": "per-particle |g32 - g64| / |g64| of the particle-space gradient [B, D] of sum_chunks ll",
+           "ours_f32_vs_ours_f64_full_batch": rel(to_particle_space(G32), to_particle_space(G64)),
+           "full_batch": f"{params.shape[0]} particles x {S} chunks x {data.shape[1]} sites (warm-up {W})"}
+    del kern64
+    # bounded sample without warm-up: ours and the reference's kernels on identical inputs
+    Sr = int(min(S, max_ref_chunks))
+    sub = np.ascontiguousarray(data[:Sr])
+    P = params.detach().cpu().numpy()
+    k32 = get_kernel(K, sub, double_precision=False, device=dev.index)
+    k64 = get_kernel(K, sub, double_precision=True, device=dev.index)
+    si = torch.arange(Sr, device=dev)
+    g32 = to_particle_space(k32.value_and_grad(pp, si)[1])
+    g64 = to_particle_space(k64.value_and_grad(pp, si)[1])
+    out["sample"] = f"{P.shape[0]} particles x {Sr} chunks x {sub.shape[1]} sites, no warm-up"
+    out["ours_f32_vs_ours_f64_sample"] = rel(g32, g64)
+    try:
+        from oracle import cport, refcuda
+
+        if refcuda.available(K, False) and refcuda.available(K, True):
+            PB = np.repeat(P[:, None], Sr, axis=1)
+            safe = np.where(PB != 0, PB, 1.0)
+
+            def ref(dbl):
+                _, dlog, _ = refcuda.call(K, dbl, sub, np.arange(Sr), PB, grad=True)
+                # d ll / d theta = dlog / theta; entries of structurally zero parameters are discarded by
+                # the reference's callers (their Jacobian rows are zero)
+                G = np.where(PB != 0, dlog.astype(np.float64) / safe, 0.0).sum(1)
+                return to_particle_space(torch.as_tensor(G))
+
+            r32, r64 = ref(False), ref(True)
+            out["reference_f32_vs_reference_f64_sample"] = rel(r32, r64)
+            out["ours_f64_vs_reference_f64_sample"] = rel(g64, r64)
+        nb = int(min(P.shape[0], max_oracle_particles))
+        _, go = cport.batch(P[:nb, None], sub, np.arange(Sr), 0)
+        (gxo,) = torch.autograd.grad(params, xs, grad_outputs=torch.cat(
+            [torch.as_tensor(go.sum(1)), torch.zeros((P.shape[0] - nb,) + go.shape[2:], dtype=torch.float64)]).to(dev),
+            retain_graph=True)
+        out["ours_f64_vs_oracle_sample"] = rel(g64[:nb], gxo[:nb])
+        out["ours_f32_vs_oracle_sample"] = rel(g32[:nb], gxo[:nb])
+    except ImportError:
+        pass
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -131,18 +235,29 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from phlash_amd import parallel, svgd
     from phlash_amd.kernel import get_kernel
-    from phlash_amd.model import log_prior
+    from phlash_amd.model import afs_term, log_prior
     from phlash_amd.param_map import particles_to_psmc
     from phlash_amd.params import PSMCParams
     from phlash_amd.synth import particle_population, simulate_chunks
 
     K, B, S, L, W = a.K, a.particles, a.chunks, a.chunk_size, a.overlap
-    # every rank owns its own S chunks of a (world x S)-chunk genome set; particles are shared
+    if a.strong:  # a fixed total of chunk rows, rank r owns rows r, r + world, ... (parallel.local_rows)
+        S_total = S
+        S = len(parallel.local_rows(S_total, rank, world))
+    else:  # every rank owns its own S chunks of a (world x S)-chunk genome set
+        S_total = world * S
+    # (rows are i.i.d. draws from the model, so "rank r's rows" is a seed; particles are shared)
     data = simulate_chunks(K, S, W + L, seed=1000 + rank)
+    afs = None
+    if a.afs_n:  # cfg3: 10 diploids -> n = 20 haploids, a smooth synthetic spectrum
+        afs = 1e5 / np.arange(1, a.afs_n, dtype=np.float64)
     template, x0 = particle_population(K, B, seed=1)
     kern = get_kernel(K, data, double_precision=a.double, overlap=W, device=local_rank)
     if a.variant:
@@ -154,13 +269,17 @@ def main():
     inds = torch.arange(S, device=dev)
     state = svgd.init(x0.to(dev))
     c1 = 1.0  # full pass: every one of the N_total chunks once -> weight N/S = 1 (mcmc.py:244)
+    flags = torch.zeros(2, dtype=torch.float64, device=dev)  # kernel flags of all steps, summed on the device
 
     def one_step(state):
         xs = state.particles.detach().requires_grad_(True)
         mcp = template.from_flat(xs)
         pp = particles_to_psmc(template, xs)  # HIP: particle -> PSMCParams (+ Jacobian), one launch
-        l2 = parallel.sharded_loglik_sum(kern, pp, inds)  # HIP kernels + the one all-reduce
+        l2 = parallel.sharded_loglik_sum(kern, pp, inds)  # HIP kernels + the one all-reduce (flags ride along)
+        flags.add_(kern._flags)
         lp = log_prior(mcp) + c1 * l2
+        if afs is not None:
+            lp = lp + afs_term(mcp.to_dm(), afs)  # model.py:58-68 (torch float64 on the GPU; tiny next to the kernels)
         (g,) = torch.autograd.grad(lp.sum(), xs)
         return svgd.step(state, g, lr=0.1)
 
@@ -185,10 +304,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
-    assert not kern._eng.underflow_risk(), "the rescale interval was too long for these particles"
+    assert float(flags[1]) == 0, "a chunk index was out of range"
+    assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
+    if use_dist and world > 1:  # the replicated state must be identical on every rank
+        lo, hi = state.particles.clone(), state.particles.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert bool((lo == hi).all()), "ranks disagree on the particles after the timed loop"
 
     if rank == 0:
-        work_per_step = world * B * S * L
+        work_per_step = B * S_total * L
         value = work_per_step * a.steps / elapsed
         rs = 8 if a.double else 4
         # dominant kernel: the backward kernel (re-runs the block forward, then sweeps back).
@@ -218,15 +343,20 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64" if a.double else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2 per GPU: 1 diploid, 3 Gb = {S} chunks x {L} scored sites (+{W} warm-up), "
+                "workload": f"{a.what} = {S} chunks x {L} scored sites (+{W} warm-up) on this rank, "
                             f"K={K}, {B} SVGD particles; full inner step (param map, HIP fwd+bwd, "
                             f"all-reduce, chain rule, SVGD update)",
-                "K": K, "particles": B, "chunks_per_gpu": S, "chunk_size": L, "overlap": W,
+                "name": a.config,
+                "K": K, "particles": B, "chunks_per_gpu": S, "chunks_total": S_total, "chunk_size": L, "overlap": W,
+                "scaling_note": ("strong scaling: the total number of chunk rows is fixed and sharded over the ranks"
+                                 if a.strong else
+                                 f"weak scaling: every rank holds its own {S} chunk rows ({S_total} in all); "
+                                 "use --config cfg3 for the fixed 5,000-row problem"),
                 "kernel_variant": {"lanes_per_sequence": R, "checkpoint_block": T,
                                    "plan": "segmented" if plan["segmented"] else ("hybrid" if plan.get("hybrid_first") else "serial"),
                                    **({"serial_sequences": plan["hybrid_first"], "segment_sweep_lanes": plan["R_segment_sweep"]}
@@ -242,6 +372,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": ("profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command on an earlier run (static file, not collected by this process)"
+                                   if traffic is not None else None),
                 "note": "algorithmic bytes = 1 B per processed site.particle (+params/grads); the scan is "
                         "VALU-issue/latency bound, not bandwidth bound (see DESIGN.md); vector-ALU view below",
                 "valu": {
@@ -263,6 +396,8 @@ def main():
             out["cpu_baseline"] = cb
             out["parity"] = {"max_rel_err_loglik_vs_f64_oracle": rel, "bar": 1e-5,
                              "sample": cb["sample"].split(",")[0]}
+            if a.config == "cfg2" and not a.double:
+                out["parity"]["grad_rel_err_particle_space"] = gradient_parity_leg(template, x0, data, W, dev, kern)
             if not a.no_reference_kernel:
                 rk = reference_kernel_leg(pp0.stack().cpu().numpy(), data, W, L, kern._eng, a.double)
                 if rk is not None:

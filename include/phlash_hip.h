@@ -61,8 +61,9 @@ int phk_destroy(phk_handle* h);
 /* One evaluation over B particles x S chunks.
  *   params     device, [B, S, 7, K] with element strides (pstride_b, pstride_s); pstride_s = 0
  *              broadcasts one [7,K] block of a particle over all S chunks.
- *   inds       device int64 [S]: row of `data` for each chunk.  The range 0 <= inds[s] < N is the
- *              caller's contract (the Python host checks it as gpu.py:197-199 before the call).
+ *   inds       device int64 [S]: row of `data` for each chunk.  0 <= inds[s] < N (gpu.py:197-199) is
+ *              checked on the device: an index outside the range is clamped to row 0 and raises
+ *              bit 1 of the flag word; the next phk_underflow_risk then returns PHK_EINVAL.
  *   W          number of leading sites of every row that are run but NOT scored (the reference's
  *              warm-up prefix, model.py:52-55).  W = 0 reproduces `loglik`/`loglik_grad` exactly:
  *              pi is the state law one transition before site 0.
@@ -103,8 +104,9 @@ int phk_set_autotune(phk_handle* h, int on);
 /* How the gradient is evaluated: 0 = serial (forward kernel, then one backward sweep per sequence:
  * best when B*S sequences fill the chip), 1 = segmented (forward kernel and an independent
  * beta-recursion kernel run concurrently on two streams, then every 512-site segment of every
- * sequence is swept in parallel: best for small batches such as the reference's 500 particles x 5
- * chunks), -1 = automatic (default; the autotuner times both where the batch is small). */
+ * sequence is swept in parallel, each unit storing its partial sums in a slot of its own that a
+ * finalize kernel adds up in unit order: best for small batches such as the reference's 500
+ * particles x 5 chunks), -1 = automatic (default; the autotuner times both where the batch is small). */
 int phk_set_backward_mode(phk_handle* h, int mode);
 /* Force a complete plan (segmented = -1 returns to automatic).  Serial: (R, T).  Segmented: R for
  * the segment sweep, R_forward for the forward kernel, R_scan for the beta scan; T (8 or 16) is
@@ -126,9 +128,23 @@ int phk_set_rescale_interval(phk_handle* h, int nrm);
  * between could have lost precision.  Reads (and clears) the flag; synchronises with the work
  * enqueued before.  The Python host re-evaluates such a call with nrm = 1. */
 int phk_underflow_risk(phk_handle* h, int* flag);
+/* The same flag word handed over WITHOUT a host synchronisation: a one-thread kernel on `stream`
+ * writes dst[0] = 1.0 if the underflow-risk bit is set (else 0.0), dst[1] = 1.0 if a chunk index was
+ * outside [0, N) (else 0.0) -- `dst` is a device array of two doubles -- and clears the word.  The
+ * multi-rank host puts `dst` inside the buffer it all-reduces (SUM) anyway, so that every rank sees the same flags and takes the same redo branch
+ * (the reference has no counterpart: its kernel objects are driven by threads of one process,
+ * gpu.py:386-438). */
+int phk_take_flags_async(phk_handle* h, double* dst, void* stream);
+/* Deterministic mode (also environment PHK_DETERMINISTIC=1): the plan comes from the static rule,
+ * never from a timing, and every reduction runs in a fixed order, so two calls with the same inputs
+ * return the same bits.  (Without it the tuner may pick different variants on different runs, and
+ * float32 variants differ in their last digits.) */
+int phk_set_deterministic(phk_handle* h, int on);
 /* Upper bound for the checkpoint workspace; larger problems are run in particle / chunk slabs. */
 int phk_set_workspace_limit(phk_handle* h, int64_t bytes);
 int64_t phk_workspace_bytes(phk_handle* h);
+/* The (particles x chunks) slab the last phk_loglik was cut into (= B x S when it ran as one launch). */
+int phk_get_slab(phk_handle* h, int64_t* particles, int64_t* chunks);
 /* With profiling on, every phk_loglik records HIP events around its kernels on the call's stream;
  * phk_last_timing waits for them and returns the summed device time of the forward and backward
  * kernels of the last call (ms) and the number of launches of each. */

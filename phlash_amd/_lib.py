@@ -31,6 +31,8 @@ SIGNATURES = {
     "phk_get_variant": (_i, [_vp, _i64, _i64, _ip, _ip]),
     "phk_set_rescale_interval": (_i, [_vp, _i]),
     "phk_underflow_risk": (_i, [_vp, _ip]),
+    "phk_take_flags_async": (_i, [_vp, _vp, _vp]),
+    "phk_set_deterministic": (_i, [_vp, _i]),
     "phk_set_autotune": (_i, [_vp, _i]),
     "phk_set_backward_mode": (_i, [_vp, _i]),
     "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),
@@ -38,6 +40,7 @@ SIGNATURES = {
     "phk_get_plan_hybrid": (_i, [_vp, ctypes.POINTER(ctypes.c_int64), _ip, _ip]),
     "phk_set_workspace_limit": (_i, [_vp, _i64]),
     "phk_workspace_bytes": (_i64, [_vp]),
+    "phk_get_slab": (_i, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "phk_set_profiling": (_i, [_vp, _i]),
     "phk_last_timing": (_i, [_vp, _fp, _fp, _ip]),
     "phk_timing_totals": (_i, [_vp, _dp, _dp, _ip]),

@@ -23,7 +23,7 @@ namespace phk {
     hipError_t launch_bwd_##tag(int R, int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st);              \
     hipError_t launch_bscan_##tag(int R, int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, \
                                   hipStream_t st);                                                                      \
-    hipError_t launch_finalize_##tag(const KArgs& a, hipStream_t st);
+    hipError_t launch_finalize_##tag(const KArgs& a, int units, hipStream_t st);
 PHK_DECL(f32_4) PHK_DECL(f32_8) PHK_DECL(f32_16) PHK_DECL(f32_32) PHK_DECL(f32_64)
 PHK_DECL(f64_4) PHK_DECL(f64_8) PHK_DECL(f64_16) PHK_DECL(f64_32) PHK_DECL(f64_64)
 #undef PHK_DECL
@@ -117,14 +117,17 @@ struct phk_handle {
     int K = 0, device = 0, dbl = 0;
     int64_t N = 0, L = 0, Lw = 0;
     uint32_t* packed = nullptr;
-    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, tune_ll, tune_grad, risk;
+    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, part, tune_ll, tune_grad, risk;
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int mode = -1;     // -1 auto, 0 serial, 1 segmented
     int has_forced_plan = 0;  // phk_set_plan: overrides everything above
     Plan forced_plan;
     int autotune = 1;  // time the candidate plans once per launch shape
+    int deterministic = 0;  // plan from the static rule only (never from a timing): same inputs -> same bits
+    hipStream_t last_stream = nullptr;  // stream of the last phk_loglik (the flag word is read behind it)
     std::map<std::pair<int64_t, int>, Plan> tuned;  // (sequences per launch, grad?) -> plan
+    int64_t last_Bs = 0, last_Ss = 0;  // particle x chunk slab of the last phk_loglik
     int64_t last_total = -1;  // B*S of the last phk_loglik and the plan it ran with
     Plan last_plan;
     hipStream_t side = nullptr;  // second stream of the segmented plan
@@ -140,7 +143,7 @@ namespace {
 typedef hipError_t (*fwd_fn)(int, int, int, bool, const phk::KArgs&, int, hipStream_t);
 typedef hipError_t (*bwd_fn)(int, int, int, const phk::KArgs&, int, int, hipStream_t);
 typedef hipError_t (*bscan_fn)(int, int, const phk::KArgs&, int64_t, void*, int32_t*, int, hipStream_t);
-typedef hipError_t (*fin_fn)(const phk::KArgs&, hipStream_t);
+typedef hipError_t (*fin_fn)(const phk::KArgs&, int, hipStream_t);
 struct Launchers {
     fwd_fn fwd = nullptr;
     bwd_fn bwd = nullptr;
@@ -208,6 +211,22 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         p.T = 8;
         p.R1 = p.R2 = h->force_R ? h->force_R : largest_R(h, 8);
         p.R = h->force_R ? h->force_R : throughput_R(h, nseq * units, 8, 2);
+        return p;
+    }
+    if (!h->force_R && !h->force_T && h->mode < 0) {
+        // What the tuner finds on this hardware, as a rule (the deterministic mode runs on it): the
+        // forward kernel with half the lanes per sequence of the sweep (its waves are alone on their
+        // SIMDs either way, and fewer lanes mean fewer instructions per site), and the sequences
+        // beyond whole rounds of 1,024 waves swept by segments (hybrid, see Plan).
+        if (p.R >= 2 && valid_R(h->K, p.R / 2) && nseq * (p.R / 2) / 64 >= 512) p.R1 = p.R / 2;
+        const int64_t per_round = 1024 * (int64_t)(64 / p.R);
+        const int64_t first = (nseq / per_round) * per_round;
+        if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rb(h, 4) &&
+            valid_T(h->K, 4, 8) && valid_R(h->K, 2)) {
+            p.hybrid_first = first;
+            p.R3 = 4;
+            p.R2 = 2;
+        }
     }
     return p;
 }
@@ -229,12 +248,15 @@ Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
         }
         return p;
     }
-    if (!h->force_R && !h->force_T && h->mode < 0) {
+    if (!h->force_R && !h->force_T && h->mode < 0 && !h->deterministic) {
         auto it = h->tuned.find({nseq, want_grad});
         if (it != h->tuned.end()) return it->second;
     }
     Plan p = static_plan(h, nseq, W);
-    if (!want_grad) p.segmented = 0;
+    if (!want_grad) {
+        p.segmented = 0;
+        p.hybrid_first = 0;
+    }
     return p;
 }
 
@@ -254,6 +276,11 @@ int ensure_scratch(phk_handle* h, int64_t nseq) {
     if ((rc = h->bseg.ensure((size_t)nseq * nsegp * K * rs)) != PHK_OK) return rc;
     if ((rc = h->bpi.ensure((size_t)nseq * K * sizeof(double))) != PHK_OK) return rc;
     return PHK_OK;
+}
+
+// partial sums of the segment sweep: one slot of [6, K] reals per (unit >= 1, sequence of the swept range)
+int ensure_part(phk_handle* h, int64_t nloc, int64_t units) {
+    return h->part.ensure((size_t)std::max<int64_t>(units - 1, 1) * (size_t)nloc * 6 * h->K * real_size(h));
 }
 
 // Enqueue one evaluation of `a` (ll, grad and scratch pointers set by the caller) under `plan`.
@@ -281,7 +308,10 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         a2.seq_begin = plan.hybrid_first;
         a2.seq_end = nseq;
         const int Rf = plan.R1 ? plan.R1 : plan.R;
-        HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));  // (float64 too: the segments add into it)
+        const int units = (int)n_units(h, plan.T, a.W);
+        if (int rc = ensure_part(h, nseq - plan.hybrid_first, units); rc != PHK_OK) return rc;
+        a2.part = h->part.p;
+        HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));  // (float64 too: unit 0 of a segment sweep adds into it)
         HIP_TRY(hipEventRecord(h->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         e = l.bscan(plan.R2, h->nrm, a2, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
@@ -291,9 +321,8 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         HIP_TRY(hipEventRecord(h->ev_fwd, st));
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fwd, 0));
-        const int units = (int)n_units(h, plan.T, a.W);
         e = l.bwd(plan.R3, plan.T, h->nrm, a2, units, nt, h->side);
-        if (e == hipSuccess) e = l.fin(a2, h->side);
+        if (e == hipSuccess) e = l.fin(a2, units, h->side);
         if (e != hipSuccess) return fail(PHK_EHIP, "segment sweep launch (hybrid, K=%d R=%d T=%d): %s", K, plan.R3, plan.T, hipGetErrorString(e));
         HIP_TRY(hipEventRecord(h->ev_join, h->side));
         e = l.bwd(plan.R, plan.T, h->nrm, a1, 0, nt, st);
@@ -312,6 +341,9 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     }
     // segmented: the beta scan needs nothing from the forward kernel -> second stream
     const int64_t seg_sites = SEG_SITES;
+    const int units = (int)n_units(h, plan.T, a.W);
+    if (int rc = ensure_part(h, nseq, units); rc != PHK_OK) return rc;
+    a.part = h->part.p;
     HIP_TRY(hipEventRecord(h->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
@@ -321,10 +353,9 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R1, plan.T, hipGetErrorString(e));
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-    const int units = (int)n_units(h, plan.T, a.W);
     e = l.bwd(plan.R, plan.T, h->nrm, a, units, nt, st);
     if (e != hipSuccess) return fail(PHK_EHIP, "segment kernel launch (K=%d R=%d T=%d units=%d): %s", K, plan.R, plan.T, units, hipGetErrorString(e));
-    e = l.fin(a, st);
+    e = l.fin(a, units, st);
     if (e != hipSuccess) return fail(PHK_EHIP, "finalize kernel launch: %s", hipGetErrorString(e));
     return PHK_OK;
 }
@@ -553,6 +584,7 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) h->ws_limit = (int64_t)(free_b / 2);
     else h->ws_limit = (int64_t)32 << 30;
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
+    if (const char* env = std::getenv("PHK_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
     if (h->risk.ensure(sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, sizeof(int)) != hipSuccess) {
         delete h;
         return fail(PHK_ENOMEM, "could not allocate the underflow flag");
@@ -613,7 +645,7 @@ int phk_destroy(phk_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fwd) (void)hipEventDestroy(h->ev_fwd);
     if (h->side) (void)hipStreamDestroy(h->side);
-    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->tune_ll, &h->tune_grad, &h->risk})
+    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->part, &h->tune_ll, &h->tune_grad, &h->risk})
         b->release();
     if (h->packed) (void)hipFree(h->packed);
     delete h;
@@ -705,8 +737,31 @@ int phk_get_plan_hybrid(phk_handle* h, int64_t* first, int* R_sweep, int* R_scan
 int phk_underflow_risk(phk_handle* h, int* flag) {
     if (!h || !flag) return fail(PHK_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipMemcpy(flag, h->risk.p, sizeof(int), hipMemcpyDeviceToHost));  // waits for the work before it
-    if (*flag) HIP_TRY(hipMemset(h->risk.p, 0, sizeof(int)));
+    // the flag word is written by kernels on the stream of the last phk_loglik (pool streams of
+    // PyTorch are non-blocking: the null stream would not wait for them), so read it behind that stream
+    int word = 0;
+    HIP_TRY(hipMemcpyAsync(&word, h->risk.p, sizeof(int), hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    if (word) {
+        HIP_TRY(hipMemsetAsync(h->risk.p, 0, sizeof(int), h->last_stream));
+        HIP_TRY(hipStreamSynchronize(h->last_stream));
+    }
+    *flag = (word & phk::FLAG_UNDERFLOW) ? 1 : 0;
+    if (word & phk::FLAG_BAD_INDEX) return fail(PHK_EINVAL, "a chunk index passed to phk_loglik was outside [0, N=%lld)", (long long)h->N);
+    return PHK_OK;
+}
+
+int phk_take_flags_async(phk_handle* h, double* dst, void* stream) {
+    if (!h || !dst) return fail(PHK_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(phk::take_flags_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)h->risk.p, dst);
+    HIP_TRY(hipGetLastError());
+    return PHK_OK;
+}
+
+int phk_set_deterministic(phk_handle* h, int on) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    h->deterministic = on ? 1 : 0;
     return PHK_OK;
 }
 
@@ -716,8 +771,15 @@ int phk_set_workspace_limit(phk_handle* h, int64_t bytes) {
     return PHK_OK;
 }
 
+int phk_get_slab(phk_handle* h, int64_t* particles, int64_t* chunks) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (particles) *particles = h->last_Bs;
+    if (chunks) *chunks = h->last_Ss;
+    return PHK_OK;
+}
+
 int64_t phk_workspace_bytes(phk_handle* h) {
-    return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap) : 0;
+    return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap + h->part.cap) : 0;
 }
 
 int phk_set_profiling(phk_handle* h, int on) {
@@ -800,6 +862,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     if (!pick_launchers(h, &l)) return fail(PHK_EUNSUPPORTED, "K=%d not compiled in", h->K);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    h->last_stream = st;
     const size_t rs = real_size(h);
     const int K = h->K;
     const bool want_grad = grad != nullptr;
@@ -851,12 +914,14 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.bpi = (double*)h->bpi.p;
         a.risk = (int*)h->risk.p;
         a.seq_begin = a.seq_end = 0;
+        a.N = h->N;
+        a.part = h->part.p;
         return a;
     };
 
     // plan for this launch shape: forced, tuned earlier, tuned now, or the static rule
     const int64_t nseq_launch = std::min(Bs, B) * std::min(Ss, S);
-    if (h->autotune && !h->has_forced_plan && !h->force_R && !h->force_T && h->mode < 0 && h->L >= 512 && nseq_launch >= 64 &&
+    if (h->autotune && !h->deterministic && !h->has_forced_plan && !h->force_R && !h->force_T && h->mode < 0 && h->L >= 512 && nseq_launch >= 64 &&
         !h->tuned.count({nseq_launch, want_grad ? 1 : 0})) {
         int rc = autotune(h, l, make_args(0, std::min(Bs, B), 0, std::min(Ss, S)), want_grad, st);
         if (rc != PHK_OK) return rc;
@@ -866,6 +931,8 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     if (plan.segmented && (!valid_R(K, plan.R1) || !valid_R(K, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
     h->last_total = B * S;
     h->last_plan = plan;
+    h->last_Bs = std::min(Bs, B);
+    h->last_Ss = std::min(Ss, S);
 
     for (int64_t b0 = 0; b0 < B; b0 += Bs) {
         const int64_t nb = std::min(Bs, B - b0);

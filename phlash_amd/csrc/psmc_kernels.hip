@@ -607,7 +607,27 @@ struct KArgs {
     // seq_end == 0 means all.  The hybrid plan sweeps one range serially and the other by segments;
     // every per-sequence array keeps its full B*S layout.
     int64_t seq_begin, seq_end;
+    int64_t N;               // rows of the observation matrix (chunk indices outside [0, N) raise FLAG_BAD_INDEX)
+    // segment sweep: unit y >= 1 of sequence seq writes its partial sums ONCE to
+    // part[((y - 1) * (seq_hi - seq_begin) + (seq - seq_begin)) * 6 * K ...] (real); unit 0 adds into
+    // gacc (it alone touches the sequence's row there); grad_finalize_kernel adds them up in unit order.
+    void* part;
 };
+
+// bits of the sticky device flag word (KArgs::risk)
+constexpr int FLAG_UNDERFLOW = 1;  // a rescale found the mass below 2^RISK_EXP (see below)
+constexpr int FLAG_BAD_INDEX = 2;  // a chunk index outside [0, N): the row was clamped to 0, the result is garbage
+
+// row of the observation matrix for chunk ss, range-checked (gpu.py:197-199 asserts this on the host;
+// here the indices live on the device, so the check does too)
+__device__ __forceinline__ int64_t checked_row(const KArgs& A, int64_t ss) {
+    int64_t row = A.inds[ss];
+    if (row < 0 || row >= A.N) {
+        if (A.risk != nullptr) atomicOr(A.risk, FLAG_BAD_INDEX);
+        row = 0;
+    }
+    return row;
+}
 
 // With rescaling only every NRM-th site the unscaled mass must survive NRM sites.  A rescale that
 // finds the total below 2^RISK_EXP means the parameters are extreme enough (emissions near the
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
     if constexpr (DENSE) lane.build_dense_fwd(rank);
-    const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
+    const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
@@ -814,7 +834,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
         (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || !(cend > 0.0)))
-        atomicOr(A.risk, 1);
+        atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
         if constexpr (CKPT) {
@@ -835,8 +855,9 @@ constexpr int bwd_waves_per_simd() { return (T * (K / R) * (int)sizeof(real) <= 
 
 // SEG = false: one unit per sequence sweeps all blocks (blockIdx.y == 0) and writes the gradient.
 // SEG = true : blockIdx.y picks a unit of A.seg_blocks blocks; it starts from the beta-scan's value
-//   at its right edge, adds its partial sums into gacc with f64 atomics, and grad_finalize_kernel
-//   writes the gradient.  Unit 0 also covers every segment up to the one holding the warm-up
+//   at its right edge, stores its partial sums once in its own slot of KArgs::part (no atomics: the
+//   sums of a sequence are added up in unit order by grad_finalize_kernel, so the result does not
+//   depend on the order the units ran in), and grad_finalize_kernel writes the gradient.  Unit 0 also covers every segment up to the one holding the warm-up
 //   boundary (the correction there makes those segments depend on each other).
 template <typename real, int K, int R, int T, int NRM, bool SEG>
 __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void bwd_kernel(KArgs A) {
@@ -859,7 +880,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     const real* prm = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
     real* etab = (real*)smem_raw + (size_t)tid * L::ETAB_STRIDE;
     lane.load(prm, rank, etab, pi);
-    const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
+    const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     const real* ck = (const real*)A.ckpt;
 
     V beta[NP], gb[NP], gd[NP], gu[NP], gv[NP], g0[NP], g1[NP];
@@ -908,6 +929,11 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
     }
     constexpr bool F64ACC = sizeof(real) == 4 || SEG;  // fold partial sums into the f64 buffer
     double* gacc = A.gacc + seq * 6 * K + rank * SPL;
+    real* part = nullptr;  // this unit's own slot of partial sums (units >= 1 of the segment sweep)
+    if constexpr (SEG) {
+        if (blockIdx.y > 0)
+            part = (real*)A.part + (((int64_t)blockIdx.y - 1) * (seq_hi - A.seq_begin) + (seq - A.seq_begin)) * 6 * K + rank * SPL;
+    }
     int since_flush = 0;
 
     real anext[SPL];
@@ -1039,19 +1065,24 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         }
         if constexpr (F64ACC) {
             since_flush += ns;
-            if (since_flush >= FLUSH_SITES || blk == blk_lo) {
+            // (units >= 1 of the segment sweep store their sums exactly once, at their left edge)
+            if ((since_flush >= FLUSH_SITES && part == nullptr) || blk == blk_lo) {
                 since_flush = 0;
                 if (active) {
 #pragma unroll
                     for (int i = 0; i < SPL; ++i) {
-                        if constexpr (SEG) {  // several units add into one sequence's sums
-                            unsafeAtomicAdd(&gacc[0 * K + i], (double)L::get(gb, i));
-                            unsafeAtomicAdd(&gacc[1 * K + i], (double)L::get(gd, i));
-                            unsafeAtomicAdd(&gacc[2 * K + i], (double)L::get(gu, i));
-                            unsafeAtomicAdd(&gacc[3 * K + i], (double)L::get(gv, i));
-                            unsafeAtomicAdd(&gacc[4 * K + i], (double)L::get(g0, i));
-                            unsafeAtomicAdd(&gacc[5 * K + i], (double)L::get(g1, i));
-                        } else {
+                        if constexpr (SEG) {
+                            if (blockIdx.y > 0) {  // one flush per unit (a unit is shorter than FLUSH_SITES): plain stores
+                                part[0 * K + i] = L::get(gb, i);
+                                part[1 * K + i] = L::get(gd, i);
+                                part[2 * K + i] = L::get(gu, i);
+                                part[3 * K + i] = L::get(gv, i);
+                                part[4 * K + i] = L::get(g0, i);
+                                part[5 * K + i] = L::get(g1, i);
+                                continue;
+                            }
+                        }
+                        {
                             gacc[0 * K + i] += (double)L::get(gb, i);
                             gacc[1 * K + i] += (double)L::get(gd, i);
                             gacc[2 * K + i] += (double)L::get(gu, i);
@@ -1141,7 +1172,7 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
 #pragma unroll
     for (int i = 0; i < SPL; ++i) L::set(beta, i, real(1));
-    const uint32_t* words = A.packed + A.inds[ss] * A.Lw;
+    const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     int F = 0;
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
     const int nw = (int)((A.Ltot + 15) / 16);
@@ -1228,22 +1259,33 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     }
 }
 
-// gacc [B*S, 6, K] + bpi [B*S, K] -> grad [B*S, 7, K]   (segmented mode)
+// gacc [B*S, 6, K] (unit 0) + part [units - 1, range, 6, K] (the other units, added in unit order:
+// the result does not depend on the order in which the units ran) + bpi [B*S, K] -> grad [B*S, 7, K]
 template <typename real>
-__global__ void grad_finalize_kernel(KArgs A, int K) {
-    const int64_t nseq = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+__global__ void grad_finalize_kernel(KArgs A, int K, int units) {
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+    const int64_t nloc = seq_hi - A.seq_begin;
     const int64_t idx = A.seq_begin * K + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nseq * K) return;
+    if (idx >= seq_hi * K) return;
     const int64_t seq = idx / K;
     const int k = (int)(idx - seq * K);
     const int64_t bb = seq / A.S, ss = seq - bb * A.S;
     const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
     const double* ga = A.gacc + seq * 6 * K;
+    const real* pt = (const real*)A.part + (seq - A.seq_begin) * 6 * K + k;
+    double sum[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sum[r] = ga[r * K + k];
+    for (int u = 1; u < units; ++u) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sum[r] += (double)pt[r * K];
+        pt += nloc * 6 * K;
+    }
     real* out = (real*)A.grad + seq * 7 * K;
     const bool dl = A.grad_dlog != 0;
-    for (int r = 0; r < 4; ++r) out[r * K + k] = (real)(dl ? ga[r * K + k] * (double)p[r * K + k] : ga[r * K + k]);
-    out[4 * K + k] = (real)(dl ? ga[4 * K + k] : ga[4 * K + k] / (double)p[4 * K + k]);
-    out[5 * K + k] = (real)(dl ? ga[5 * K + k] : ga[5 * K + k] / (double)p[5 * K + k]);
+    for (int r = 0; r < 4; ++r) out[r * K + k] = (real)(dl ? sum[r] * (double)p[r * K + k] : sum[r]);
+    out[4 * K + k] = (real)(dl ? sum[4] : sum[4] / (double)p[4 * K + k]);
+    out[5 * K + k] = (real)(dl ? sum[5] : sum[5] / (double)p[5 * K + k]);
     const double bp = A.bpi[seq * K + k];
     out[6 * K + k] = (real)(dl ? bp * (double)p[6 * K + k] : bp);
 }
@@ -1253,6 +1295,14 @@ __global__ void grad_finalize_kernel(KArgs A, int K) {
 // (a plain, non-template kernel: emitted only in the translation unit that defines PHK_WITH_PACK)
 // ---------------------------------------------------------------------------------------------
 #ifdef PHK_WITH_PACK
+// stream-ordered hand-over of the flag word, one double per bit (so that the bits survive the SUM
+// all-reduce of the float64 buffer they ride in): dst[0] = underflow risk, dst[1] = bad index; flags = 0
+__global__ void take_flags_kernel(int* flags, double* dst) {
+    const int w = atomicExch(flags, 0);
+    dst[0] = (w & FLAG_UNDERFLOW) ? 1.0 : 0.0;
+    dst[1] = (w & FLAG_BAD_INDEX) ? 1.0 : 0.0;
+}
+
 __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t L, uint32_t* __restrict__ out,
                             int64_t Lw) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

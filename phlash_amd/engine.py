@@ -80,6 +80,16 @@ class HipEngine:
         _lib.check(_lib.load().phk_underflow_risk(self._h, ctypes.byref(f)))
         return bool(f.value)
 
+    def take_flags_async(self, dst: torch.Tensor):
+        """Stream-ordered, no host synchronisation: dst[0] = 1.0 on underflow risk, dst[1] = 1.0 if a
+        chunk index was out of range (``dst``: two contiguous float64 on the device); clears the flags."""
+        assert dst.is_cuda and dst.dtype == torch.float64 and dst.numel() == 2 and dst.is_contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.load().phk_take_flags_async(self._h, dst.data_ptr(), ctypes.c_void_p(stream)))
+
+    def set_deterministic(self, on: bool):
+        _lib.check(_lib.load().phk_set_deterministic(self._h, int(bool(on))))
+
     def set_autotune(self, on: bool):
         _lib.check(_lib.load().phk_set_autotune(self._h, int(bool(on))))
 
@@ -110,6 +120,13 @@ class HipEngine:
 
     def workspace_bytes(self) -> int:
         return int(_lib.load().phk_workspace_bytes(self._h))
+
+    def get_slab(self) -> tuple[int, int]:
+        """(particles, chunks) per launch of the last call (the checkpoint store is cut into slabs
+        when it would exceed the workspace limit)."""
+        b, c = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().phk_get_slab(self._h, ctypes.byref(b), ctypes.byref(c)))
+        return b.value, c.value
 
     def set_profiling(self, on: bool):
         _lib.check(_lib.load().phk_set_profiling(self._h, int(bool(on))))

@@ -36,7 +36,12 @@ def _as_tensor(a, device):
 def _run_guarded(kern, *args, **kw):
     """engine.run with the safety net of the rescale interval: if the forward kernel reports that the
     parameters are too extreme for rescaling every few sites only, switch this kernel object to
-    per-site rescaling (the reference's schedule, hmm.py:77-79) for good and evaluate again."""
+    per-site rescaling (the reference's schedule, hmm.py:77-79) for good and evaluate again.
+    Rank-local on purpose: ``loglik`` / ``__call__`` contain no collective, so a rank may redo its own
+    evaluation without its peers.  The sharded evaluation (``parallel.py``, used by ``fit``) must NOT
+    decide locally -- its redo contains an all-reduce -- and carries the flags in that all-reduce
+    instead (``take_flags_into`` / ``check_rescaling(collective=True)``).  A chunk index outside
+    [0, N) surfaces here as AssertionError (gpu.py:197-199)."""
     out = kern._eng.run(*args, **kw)
     if kern._eng.underflow_risk():
         warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
@@ -81,9 +86,13 @@ class PSMCKernel:
             out with one process per GPU (``phlash_amd.parallel``), not with threads.
         overlap: number of leading warm-up sites in every row (extension, default 0).
         device: HIP device ordinal (default: torch's current device).
+        keep_host_data: keep a host copy of ``data`` as ``.host_data`` (needed only by the
+            reference-style two-step ``log_density(mcp, c, inds, warmup, kern)`` call form,
+            model.py:52-57, which concatenates warm-up columns to rows of the kernel's data).
     """
 
-    def __init__(self, M, data, double_precision=False, num_gpus: int = None, overlap: int = 0, device=None):
+    def __init__(self, M, data, double_precision=False, num_gpus: int = None, overlap: int = 0, device=None,
+                 keep_host_data: bool = False):
         if num_gpus is not None:
             assert num_gpus > 0  # gpu.py:340-341
             if num_gpus > 1:
@@ -105,6 +114,10 @@ class PSMCKernel:
         self.M = M
         self.double_precision = double_precision
         self.overlap = int(overlap)
+        self.host_data = None
+        if keep_host_data:
+            self.host_data = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.array(data, copy=True)
+        self._flags = None  # [2] float64 on the device: flags of the evaluations since the last check
         self._eng = HipEngine(M, data, double_precision=double_precision, device=device)
         self.N, self.L = self._eng.N, self._eng.L
         assert 0 <= self.overlap <= self.L
@@ -194,24 +207,59 @@ class PSMCKernel:
         return ll, dll
 
     # ---- fused evaluation used by the sampler -------------------------------------------------
-    def value_and_grad(self, pp: PSMCParams, inds: torch.Tensor, reduce_chunks: bool = True):
+    def _inds_tensor(self, inds) -> torch.Tensor:
+        if isinstance(inds, torch.Tensor):  # device-resident indices are range-checked on the device
+            return inds.to(device=self.device, dtype=torch.int64)
+        a = np.atleast_1d(np.asarray(inds, dtype=np.int64))
+        if a.size:  # host indices: the reference's assert (gpu.py:197-199), free here
+            assert 0 <= a.min() and a.max() < self.N, f"0 <= {a.min()} <= {a.max()} < N={self.N}"
+        return torch.as_tensor(a, dtype=torch.int64, device=self.device)
+
+    def value_and_grad(self, pp: PSMCParams, inds, reduce_chunks: bool = True):
         """One particle population against a minibatch: pp fields [B, M] -> (ll, d ll / d params).
         With ``reduce_chunks`` the sum over the S chunks is taken here (ll [B], grad [B, 7, M]
         float64) -- the quantity model.log_density needs (model.py:57 ``.sum()``).  Asynchronous: no
-        host synchronisation, hence no underflow check here; ``fit`` calls ``check_rescaling()`` once per
-        iteration, where it synchronises anyway."""
+        host synchronisation, hence no underflow / index check here: the flags stay on the device until
+        ``take_flags_into`` (inside the sharded evaluation) or ``check_rescaling`` collects them; ``fit``
+        does that once per iteration, where it synchronises anyway."""
         pa = torch.stack([_as_tensor(a, self.device) for a in pp], -2)[:, None]
         with torch.no_grad():
-            ll, g = self._eng.run(pa, inds, warmup=self.overlap, grad=True, dlog=False)
+            ll, g = self._eng.run(pa, self._inds_tensor(inds), warmup=self.overlap, grad=True, dlog=False)
         if reduce_chunks:
             return ll.sum(1), g.sum(1, dtype=F64)
         return ll, g
 
+    def value(self, pp: PSMCParams, inds, reduce_chunks: bool = True):
+        """The same without the gradient: the no-gradient kernel only (no checkpoint store, no
+        backward sweep) -- what the reference's primal rule runs (gpu.py:446-449), e.g. for the ELPD
+        of held-out data (mcmc.py:224-238)."""
+        pa = torch.stack([_as_tensor(a, self.device) for a in pp], -2)[:, None]
+        with torch.no_grad():
+            ll = self._eng.run(pa, self._inds_tensor(inds), warmup=self.overlap, grad=False)
+        return ll.sum(1) if reduce_chunks else ll
 
-    def check_rescaling(self) -> bool:
+    def take_flags_into(self, dst: torch.Tensor):
+        """Stream-ordered (no host sync): move this kernel object's flags (underflow risk, bad chunk
+        index) into ``dst`` ([2] float64 on the device, e.g. a slice of the buffer about to be
+        all-reduced) and remember ``dst`` as the place ``check_rescaling(collective=True)`` reads."""
+        self._eng.take_flags_async(dst)
+        self._flags = dst
+
+    def check_rescaling(self, collective: bool = False) -> bool:
         """True (after switching to per-site rescaling) if an evaluation since the last check hit
-        parameters too extreme for the current rescale interval; the caller should redo that step."""
-        if self._eng.underflow_risk():
+        parameters too extreme for the current rescale interval; the caller should redo that step.
+        ``collective``: decide from the flags that travelled in the last all-reduce
+        (``take_flags_into``), which are the same on every rank, so that all ranks take the same
+        branch -- a rank-local decision followed by a redo that contains a collective would desynchronise
+        the ranks.  Raises AssertionError if a chunk index was out of range (gpu.py:197-199)."""
+        if collective and self._flags is not None:
+            under, bad = (float(v) for v in self._flags.cpu())  # synchronises
+            self._flags = None
+            assert bad == 0, f"a chunk index was outside [0, N={self.N})"
+            risk = under > 0
+        else:
+            risk = self._eng.underflow_risk()
+        if risk:
             warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
             self._eng.set_rescale_interval(1)
             return True

@@ -12,15 +12,20 @@ Differences from the reference, all deliberate:
 * under ``torchrun`` (one process per GPU) the work is sharded across ranks -- by chunk rows when the
   minibatch has at least as many chunks as ranks, otherwise by particles (option ``shard``:
   "auto" | "chunks" | "particles") -- and each step ends in one all-reduce (``parallel.py``); all
-  ranks return the same particles.
+  ranks return the same particles.  ``fit`` joins the process group itself when it finds torchrun's
+  environment (RANK / WORLD_SIZE / LOCAL_RANK) and nobody has initialised ``torch.distributed`` yet:
+  backend "nccl" (= RCCL) bound to GPU LOCAL_RANK.  The reference drives all GPUs from one process
+  with threads instead (gpu.py:386-438).
 """
 
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import parallel, svgd
 from .afs import bws_transform, fold_transform
@@ -47,6 +52,30 @@ def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, a
     return torch.where(torch.isfinite(ret), ret, torch.full_like(ret, -float("inf")))
 
 
+def _join_process_group() -> int:
+    """Under torchrun (RANK / WORLD_SIZE in the environment) bind this process to GPU LOCAL_RANK and
+    join the process group if the caller has not done so; returns the device ordinal to use.  Without
+    this, every rank of a ``torchrun`` launch that simply calls ``fit`` would run the whole, unsharded
+    problem on GPU 0."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: phlash_amd.fit needs an MI355X (there is no CPU fallback)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1 and "LOCAL_RANK" in os.environ:
+            torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        return torch.cuda.current_device()
+    if world > 1:
+        if "RANK" not in os.environ:
+            raise RuntimeError("WORLD_SIZE > 1 but RANK is not set: launch with torchrun (one process per GPU)")
+        local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=world,
+                                device_id=torch.device("cuda", local))  # "nccl" is RCCL on ROCm
+    return torch.cuda.current_device()
+
+
 def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     """Sample demographic models from the posterior.
 
@@ -62,6 +91,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     Returns:
         list of ``DemographicModel`` (one per particle), rates per base pair.
     """
+    device_index = _join_process_group()
     seed = options.get("key", 1)
     if not isinstance(seed, (int, np.integer)):
         seed = int(np.asarray(seed).ravel()[-1])
@@ -122,7 +152,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     ndim = x0.shape[0]
     num_particles = options.get("num_particles", 500)
     noise = rng.standard_normal(size=(num_particles, ndim)) * np.sqrt(options.get("sigma", 1.0))
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", device_index)
     x = (x0[None] + torch.as_tensor(noise, dtype=F64)).to(dev)
     template = MCMCParams(pattern=init.pattern, t_tr=None, c_tr=None, rho_over_theta_tr=None,
                           theta=init.theta, alpha=init.alpha, beta=init.beta)
@@ -137,7 +167,10 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     assert np.all(chunks[:, overlap:].max(axis=1) > -1), "data contains observations with all missing values"
     mine = np.arange(N) if by_particles else parallel.local_rows(N, rank, size)
     train_kern = get_kernel(M=M, data=np.ascontiguousarray(chunks[mine]),
-                            double_precision=options.get("double_precision", False), overlap=overlap)
+                            double_precision=options.get("double_precision", False), overlap=overlap,
+                            device=device_index)
+    if options.get("deterministic"):  # extension: static plan, fixed-order reductions (bit-reproducible runs)
+        train_kern._eng.set_deterministic(True)
 
     elpd = None
     if test_data:
@@ -148,24 +181,37 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
         # reference: warm-up = one all-missing column (mcmc.py:230-233) -> prepend it, overlap = 1
         test_rows = np.concatenate([np.full((N_test, 1), -1, np.int8), test_rows.clip(-1, 1).astype(np.int8)], 1)
         t_mine = np.arange(N_test) if by_particles else parallel.local_rows(N_test, rank, size)
-        test_kern = get_kernel(M=M, data=np.ascontiguousarray(test_rows[t_mine]), double_precision=False, overlap=1) \
-            if len(t_mine) else None
+        test_kern = get_kernel(M=M, data=np.ascontiguousarray(test_rows[t_mine]), double_precision=False, overlap=1,
+                               device=device_index) if len(t_mine) else None
+        if test_kern is not None and options.get("deterministic"):
+            test_kern._eng.set_deterministic(True)
         c_elpd = torch.tensor([0.0, 1.0, 1.0], dtype=F64, device=dev)
 
-        def elpd(xs):
+        def elpd_once(xs):
+            # autograd is off: only the no-gradient kernel runs (parallel.sharded_loglik_sum), as in the
+            # reference's primal rule (gpu.py:446-449)
             with torch.no_grad():
                 if by_particles:
                     idx = torch.arange(rank, xs.shape[0], size, device=xs.device)
-                    tot = torch.zeros(1, dtype=F64, device=xs.device)
+                    tot = torch.zeros(3, dtype=F64, device=xs.device)
                     if idx.numel():
-                        tot += _log_density_population(xs[idx], template, c_elpd, test_kern, np.arange(N_test),
-                                                       test_afs, afs_transform, reduce=False).sum()
-                    return float(parallel.all_reduce_sum_(tot)) / xs.shape[0]
+                        tot[0] = _log_density_population(xs[idx], template, c_elpd, test_kern, np.arange(N_test),
+                                                         test_afs, afs_transform, reduce=False).sum()
+                    test_kern.take_flags_into(tot[1:])  # rides in the same all-reduce
+                    parallel.all_reduce_sum_(tot)
+                    return tot[0] / xs.shape[0], test_kern
                 if test_kern is None:  # more ranks than test rows: contribute zeros to the all-reduce
                     k_, li = train_kern, np.zeros(0, np.int64)
                 else:
                     k_, li = test_kern, np.arange(len(t_mine))
-                return float(_log_density_population(xs, template, c_elpd, k_, li, test_afs, afs_transform).mean())
+                return _log_density_population(xs, template, c_elpd, k_, li, test_afs, afs_transform).mean(), k_
+
+        def elpd(xs):
+            val, k_ = elpd_once(xs)
+            if k_.check_rescaling(collective=True):  # same decision on every rank (flags were all-reduced)
+                val, k_ = elpd_once(xs)
+                k_.check_rescaling(collective=True)
+            return float(val)
 
     c_train = torch.tensor([1.0, N / S, 1.0], dtype=F64, device=dev)  # mcmc.py:240-247
 
@@ -190,28 +236,29 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             it = tqdm.trange(niter, desc="Fitting model")
         except ImportError:
             pass
-    for i in it:
-        inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
+    def grad_logp(inds):
+        """d log density / d particles for this minibatch [B, D]; ends in exactly one all-reduce."""
         if by_particles:
             _, g = parallel.particle_sharded_value_and_grad(
                 lambda xl: _log_density_population(xl, template, c_train, train_kern, inds, afs, afs_transform,
                                                    reduce=False),
-                state.particles)
-        else:
-            local = parallel.split_minibatch(inds, rank, size)
-            xs = state.particles.detach().requires_grad_(True)
-            lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
-            (g,) = torch.autograd.grad(lp.sum(), xs)
-        if train_kern.check_rescaling():  # extreme particle: the kernel now rescales every site; redo
-            if by_particles:
-                _, g = parallel.particle_sharded_value_and_grad(
-                    lambda xl: _log_density_population(xl, template, c_train, train_kern, inds, afs, afs_transform,
-                                                       reduce=False),
-                    state.particles)
-            else:
-                xs = state.particles.detach().requires_grad_(True)
-                lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
-                (g,) = torch.autograd.grad(lp.sum(), xs)
+                state.particles, kern=train_kern)
+            return g
+        local = parallel.split_minibatch(inds, rank, size)
+        xs = state.particles.detach().requires_grad_(True)
+        lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
+        (g,) = torch.autograd.grad(lp.sum(), xs)
+        return g
+
+    for i in it:
+        inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
+        g = grad_logp(inds)
+        # An extreme particle may need per-site rescaling (the kernel raises a device flag).  The flag
+        # travelled in the step's all-reduce, so every rank reads the same value here and all of them
+        # redo the step (which contains another all-reduce) or none does.
+        if train_kern.check_rescaling(collective=True):
+            g = grad_logp(inds)
+            train_kern.check_rescaling(collective=True)
         state = svgd.step(state, g, lr)
         assert bool(torch.isfinite(state.particles).all())  # mcmc.py:281-285
         if elpd is not None and i % 10 == 0:

@@ -23,6 +23,10 @@ Chunk mode:
 * every rank evaluates all particles on its chunks and the partial sums [B, 1 + 7K] are combined by
   a single ``all_reduce(SUM)`` (RCCL over xGMI on GPUs; gloo in the CPU tests).  At 45-450 KB the
   message is latency-bound; everything after it is replicated deterministically.
+* the same buffer carries one more row: the kernels' sticky flags (underflow risk of the rescale
+  interval, chunk index out of range), handed over on the device without a host sync.  After the
+  all-reduce every rank holds the same flags, so the decision to redo a step with per-site rescaling
+  -- a redo that itself contains an all-reduce -- is taken identically everywhere.
 """
 
 from __future__ import annotations
@@ -56,25 +60,38 @@ def all_reduce_sum_(buf: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+def _take_flags(kern, dst: torch.Tensor):
+    """Put the kernel object's device flags (underflow risk, bad chunk index) into ``dst`` ([2] f64)
+    without a host sync, so that they ride in the all-reduce that follows and every rank later takes
+    the same redo decision (``PSMCKernel.check_rescaling(collective=True)``)."""
+    take = getattr(kern, "take_flags_into", None)
+    if take is not None:
+        take(dst)
+
+
 class _ShardedLogLikSum(torch.autograd.Function):
     """sum over ALL ranks' chunks of the per-particle log-likelihood, with its gradient w.r.t. the
-    [B, 7, K] parameter block -- value and gradient travel in one all-reduce."""
+    [B, 7, K] parameter block -- value, gradient and the kernels' flags travel in one all-reduce of a
+    [B + 1, 1 + 7K] float64 buffer (row B: flags)."""
 
     @staticmethod
-    def forward(ctx, params, evaluate, local_inds, reduce=True):
+    def forward(ctx, params, evaluate, local_inds, reduce=True, kern=None):
         # evaluate(params [B,7,K], local_inds) -> (ll_sum [B] f64, grad_sum [B,7,K] f64), local chunks only
         ll, g = evaluate(params, local_inds)
         B = params.shape[0]
-        buf = torch.cat([ll.reshape(B, 1), g.reshape(B, -1)], 1).contiguous()
-        if reduce:
+        buf = torch.zeros((B + 1, 1 + g[0].numel()), dtype=torch.float64, device=ll.device)
+        buf[:B, 0] = ll
+        buf[:B, 1:] = g.reshape(B, -1)
+        if reduce:  # (reduce=False: the flags stay on the device for the caller's own collective to collect)
+            _take_flags(kern, buf[B, :2])
             all_reduce_sum_(buf)
-        ctx.save_for_backward(buf[:, 1:].reshape(g.shape))
-        return buf[:, 0].clone()
+        ctx.save_for_backward(buf[:B, 1:].reshape(g.shape))
+        return buf[:B, 0].clone()
 
     @staticmethod
     def backward(ctx, gll):
         (g,) = ctx.saved_tensors
-        return gll[:, None, None] * g, None, None, None
+        return gll[:, None, None] * g, None, None, None, None
 
 
 def shard_mode(minibatch_size: int, size: int, requested: str = "auto") -> str:
@@ -84,40 +101,56 @@ def shard_mode(minibatch_size: int, size: int, requested: str = "auto") -> str:
     return "chunks" if minibatch_size >= size else "particles"
 
 
-def particle_sharded_value_and_grad(logp_fn, x: torch.Tensor):
+def particle_sharded_value_and_grad(logp_fn, x: torch.Tensor, kern=None):
     """logp_fn(x_local [Bl, D]) -> [Bl] (differentiable).  Every rank evaluates particles
     rank, rank+W, ...; returns (logp [B], grad [B, D]) identical on all ranks, assembled with ONE
-    all-reduce of a zero-padded [B, 1 + D] buffer."""
+    all-reduce of a zero-padded [B + 1, 1 + D] buffer (row B: the flags of ``kern``, the kernel object
+    ``logp_fn`` evaluates with, so that the ranks agree on a redo)."""
     rank, size = world()
     B, D = x.shape
     idx = torch.arange(rank, B, size, device=x.device)
     xl = x.detach()[idx].requires_grad_(True)
-    buf = torch.zeros((B, 1 + D), dtype=x.dtype, device=x.device)
+    buf = torch.zeros((B + 1, 1 + D), dtype=x.dtype, device=x.device)
     if idx.numel():
         lp = logp_fn(xl)
         (g,) = torch.autograd.grad(lp.sum(), xl)
         buf[idx, 0] = lp.detach()
         buf[idx, 1:] = g
+    if kern is not None and x.is_cuda:
+        _take_flags(kern, buf[B, :2])
     all_reduce_sum_(buf)
-    return buf[:, 0], buf[:, 1:]
+    return buf[:B, 0], buf[:B, 1:]
 
 
 def sharded_loglik_sum(kern, pp, local_inds, reduce: bool = True) -> torch.Tensor:
     """pp: PSMCParams with fields [B, K] (one block per particle).  Returns [B]: the log-likelihood
     summed over the chunks of every rank (``reduce=False``: of this rank only -- particle mode).
-    ``kern`` holds this rank's rows."""
+    ``kern`` holds this rank's rows.  Where no gradient is wanted (autograd off, or parameters that do
+    not require one: the ELPD of held-out data, mcmc.py:224-238) only the no-gradient kernel runs,
+    as in the reference's primal rule (gpu.py:446-449), and only [B] values (+ flags) are reduced."""
     from .params import PSMCParams  # noqa: F401  (type only)
 
     params = pp.stack().to(kern.device)
+    if isinstance(local_inds, torch.Tensor):
+        local_inds = local_inds.to(device=kern.device, dtype=torch.int64)
+    else:
+        local_inds = np.asarray(local_inds, dtype=np.int64)
+    empty = (local_inds.numel() if isinstance(local_inds, torch.Tensor) else local_inds.size) == 0
+    B = params.shape[0]
+
+    if not (torch.is_grad_enabled() and params.requires_grad) and hasattr(kern, "value"):
+        buf = torch.zeros(B + 2, dtype=torch.float64, device=kern.device)
+        if not empty:
+            buf[:B] = kern.value(PSMCParams.unstack(params.detach()), local_inds, reduce_chunks=True)
+        if reduce:  # (reduce=False: the flags stay on the device for the caller's own collective to collect)
+            _take_flags(kern, buf[B:])
+            all_reduce_sum_(buf)
+        return buf[:B]
 
     def evaluate(p, inds):
-        if isinstance(inds, torch.Tensor):
-            inds = inds.to(device=kern.device, dtype=torch.int64)
-        else:
-            inds = torch.as_tensor(np.asarray(inds), dtype=torch.int64, device=kern.device)
-        if inds.numel() == 0:
+        if empty:
             z = torch.zeros(p.shape[0], dtype=torch.float64, device=kern.device)
             return z, torch.zeros(p.shape, dtype=torch.float64, device=kern.device)
         return kern.value_and_grad(PSMCParams.unstack(p), inds, reduce_chunks=True)
 
-    return _ShardedLogLikSum.apply(params, evaluate, local_inds, reduce)
+    return _ShardedLogLikSum.apply(params, evaluate, local_inds, reduce, kern)

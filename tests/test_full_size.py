@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full sizes (cfg1, cfg2, cfg4, cfg5 shapes).  The float64 oracle is
+"""GPU tests at BASELINE.json's full sizes (cfg1, cfg2, one rank's share of cfg3, cfg4, cfg5).  The float64 oracle is
 too slow to check every sequence at these sizes, so it checks a bounded sample and the rest is
 covered by size-independent properties of the domain:
 
@@ -127,24 +127,114 @@ def test_split_additivity_and_directional_derivative():
     np.testing.assert_allclose(an.cpu(), fd.cpu(), rtol=2e-6, atol=1e-3)
 
 
-def test_cfg4_K64_and_cfg5_K32_shapes():
-    """cfg4 (K = 64, 100 particles) and cfg5 (K = 32, 500 particles) with fewer chunks; cfg5's
-    checkpoint store is cut into particle slabs by a small workspace limit."""
-    for K, B, S in ((64, 100, 24), (32, 500, 12)):
-        data, P, eng = _setup(K, B, S, 60_000, 500, False)
-        inds = torch.arange(S, device="cuda")
-        if K == 32:
-            eng.set_workspace_limit(2 << 30)
-        ll, g = eng.run(P, inds, 500, grad=True)
-        assert torch.isfinite(ll).all() and torch.isfinite(g).all()
-        sub = [0, B // 2, B - 1]
-        ll_ref, g_ref = cport.batch(P[sub].cpu().numpy(), data, [0, S - 1], 500)
-        np.testing.assert_allclose(ll[sub][:, [0, S - 1]].cpu().numpy(), ll_ref, rtol=1e-5)
-        gg = g[sub][:, [0, S - 1]].double().cpu().numpy()
-        scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
-        assert (np.abs(gg - g_ref) / scale).max() < 2e-3
-        if K == 32:
-            assert eng.workspace_bytes() < (3 << 30)
+def _sample_points(eng, B, S, slab_particles=None):
+    """Particles x chunks for the bounded oracle sample: both ends of the batch, both sides of the
+    hybrid plan's split (sequence index hybrid_first = b * S + s inside a slab) and both sides of a
+    workspace-slab boundary."""
+    plan = eng.get_plan()
+    parts, chunks = {0, B // 2, B - 1}, {0, S // 3, S - 1}
+    first = plan.get("hybrid_first", 0)
+    if first:
+        b, s = divmod(first, S)
+        parts |= {min(b, B - 1), max(b - 1, 0)}
+        chunks |= {s, max(s - 1, 0)}
+    if slab_particles and slab_particles < B:
+        parts |= {slab_particles - 1, slab_particles}
+    return sorted(parts), sorted(chunks), plan
+
+
+def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False):
+    """One whole BASELINE config through the float32 kernels at full size: finite everywhere, a bounded
+    oracle sample (ll <= 1e-5 relative, gradient 2e-3 row-scaled), gradient call == no-gradient call, and
+    the two size-independent identities of a W = 0 sweep over the whole batch."""
+    data, P, eng = _setup(K, B, S, L, W, False, seed=seed)
+    inds = torch.arange(S, device="cuda")
+    ll, g = eng.run(P, inds, W, grad=True)
+    assert torch.isfinite(ll).all() and torch.isfinite(g).all()
+    slab, slab_chunks = eng.get_slab()
+    if expect_slabs:
+        assert slab < B and slab_chunks == S, "expected the checkpoint store to need particle slabs"
+    else:
+        assert (slab, slab_chunks) == (B, S)
+    parts, chunks, plan = _sample_points(eng, B, S, slab)
+    ll_ref, g_ref = cport.batch(P[parts].float().double().cpu().numpy(), data, chunks, W)
+    got = ll[parts][:, chunks].cpu().numpy()
+    rel = np.abs(got / ll_ref - 1).max()
+    gg = g[parts][:, chunks].double().cpu().numpy()
+    scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+    gerr = (np.abs(gg - g_ref) / scale).max()
+    print(f"K={K} B={B} S={S}: plan {plan}; oracle sample {len(parts)} x {len(chunks)}: ll rel {rel:.2e}, grad {gerr:.2e}")
+    assert rel < 1e-5 and gerr < 2e-3
+    ll0 = eng.run(P, inds, W, grad=False)
+    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-6, atol=2e-3)
+    del g, ll0
+    # W = 0 over the whole batch, theta * d ll / d theta: sum_i pi_i dll/dpi_i = 1, and the emission rows
+    # add up to the number of observed sites (the posterior state marginals sum to 1 at every site)
+    llw, gl = eng.run(P, inds, 0, grad=True, dlog=True)
+    pi_sum = gl[:, :, 6, :].double().sum(-1)
+    gamma = gl[:, :, 4, :].double().sum(-1) + gl[:, :, 5, :].double().sum(-1)
+    n_obs = torch.tensor((data >= 0).sum(1), dtype=torch.float64, device="cuda")[None]
+    e_pi = float((pi_sum - 1).abs().max())
+    e_ga = float((gamma / n_obs - 1).abs().max())
+    print(f"   W=0 identities: |sum pi dll/dpi - 1| {e_pi:.2e}, |sum gamma / n_obs - 1| {e_ga:.2e}")
+    assert e_pi < 2e-3 and e_ga < 2e-3
+    return eng
+
+
+def test_cfg4_full_size():
+    """cfg4: K = 64 (fine time grid), 3 Gb = 500 chunks x 60,000 scored sites (+500 warm-up), 100 particles."""
+    _full_size_case(64, 100, 500, 60_000, 500)
+
+
+def test_cfg5_full_size():
+    """cfg5: 500 particles, K = 32, 500 chunks x 60,000 (+500): 250,000 sequences whose checkpoint
+    store (242 GB) exceeds the default workspace limit (half the free memory), so the call is cut into
+    particle slabs by the library itself -- no artificial limit."""
+    _full_size_case(32, 500, 500, 60_000, 500, expect_slabs=True)
+
+
+def test_cfg3_one_rank_share_through_log_density():
+    """cfg3: 10 diploids x 3 Gb = 5,000 chunks, K = 16, 100 particles, sharded over 8 GPUs by chunk
+    rows: one rank's share is 625 rows.  The whole objective (prior + HMM term + AFS term for n = 20
+    haploids, model.py:24-73) with its gradient w.r.t. the particles, at full size on this rank; the HMM
+    term against a bounded oracle sample, the AFS term against the same torch definition on the CPU."""
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.model import afs_term, log_density, log_prior
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import particle_population, simulate_chunks
+
+    K, B, S, L, W = 16, 100, 625, 60_000, 500
+    data = simulate_chunks(K, S, W + L, seed=3)  # rows 3, 11, 19, ... of the 5,000 (round-robin ownership)
+    tmpl, x = particle_population(K, B, seed=1, sigma=0.25)
+    rng = np.random.default_rng(0)
+    afs = rng.integers(50, 5000, size=19).astype(np.float64) / np.arange(1, 20)  # n = 20: 19 entries
+    kern = get_kernel(K, data, double_precision=False, overlap=W)
+    xs = x.cuda().requires_grad_(True)
+    c = (1.0, 5000 / S, 1.0)
+    inds = torch.arange(S, device="cuda")
+    lp = log_density(tmpl.from_flat(xs), c, inds, None, kern, afs=afs)
+    (gx,) = torch.autograd.grad(lp.sum(), xs)
+    assert lp.shape == (B,) and torch.isfinite(lp).all() and torch.isfinite(gx).all()
+    assert not kern.check_rescaling()
+    # recomposition: the three terms separately
+    with torch.no_grad():
+        mcp = tmpl.from_flat(x.cuda())
+        pp = PSMCParams.from_dm(mcp.to_dm())
+        ll, g = kern.value_and_grad(pp, inds, reduce_chunks=False)
+        l1, l3 = log_prior(mcp), afs_term(mcp.to_dm(), afs)
+        np.testing.assert_allclose(lp.detach().cpu(), (c[0] * l1 + c[1] * ll.sum(1) + c[2] * l3).cpu(), rtol=1e-9)
+        l3_cpu = afs_term(tmpl.from_flat(x).to_dm(), afs)
+        np.testing.assert_allclose(l3.cpu(), l3_cpu, rtol=1e-10)
+    parts, chunks = [0, 49, 99], [0, 200, 401, 624]
+    ll_ref, g_ref = cport.batch(pp.stack()[parts].float().double().cpu().numpy()[:, None], data, chunks, W)
+    rel = np.abs(ll[parts][:, chunks].cpu().numpy() / ll_ref - 1).max()
+    scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+    gerr = (np.abs(g[parts][:, chunks].double().cpu().numpy() - g_ref) / scale).max()
+    print(f"cfg3 share: plan {kern._eng.get_plan()}; ll rel {rel:.2e}, grad {gerr:.2e}")
+    assert rel < 1e-5 and gerr < 2e-3
+    # the ELPD-style evaluation (no gradient) gives the same HMM term from the no-gradient kernel
+    with torch.no_grad():
+        np.testing.assert_allclose(kern.value(pp, inds).cpu(), ll.sum(1).cpu(), rtol=1e-7)
 
 
 def test_cfg2_full_batch_hybrid_plan(monkeypatch):

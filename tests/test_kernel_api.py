@@ -141,8 +141,10 @@ def test_log_density_fused_and_two_step(rng):
     fused = get_kernel(16, chunks, True, overlap=W)
     v1 = log_density(init.from_flat(X), c, inds, None, fused, afs=np.ones(1))
     np.testing.assert_allclose(v1.cpu(), want, rtol=1e-9)
-    plain = get_kernel(16, np.ascontiguousarray(chunks[:, W:]), True)
-    plain.host_data = np.ascontiguousarray(chunks[:, W:])
+    plain = get_kernel(16, np.ascontiguousarray(chunks[:, W:]), True, keep_host_data=True)
+    with pytest.raises(ValueError, match="keep_host_data"):  # the two-step form needs the host copy
+        log_density(init.from_flat(X), c, inds, chunks[inds][:, :W], get_kernel(16, np.ascontiguousarray(chunks[:, W:]), True),
+                    afs=np.ones(1))
     v2 = log_density(init.from_flat(X), c, inds, chunks[inds][:, :W], plain, afs=np.ones(1))
     np.testing.assert_allclose(v2.cpu(), want, rtol=1e-9)
     # gradient w.r.t. the particles through the kernel == autograd through the oracle's recursion

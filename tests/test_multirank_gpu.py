@@ -1,0 +1,101 @@
+"""The multi-rank path on the REAL kernels: two fresh child processes (tests/mr_worker.py) share the one
+GPU of the test box through the gloo backend (RCCL refuses two ranks on one device; gloo all-reduces
+CUDA tensors) and run ``phlash_amd.fit`` sharded by chunks and by particles.  Every run must reproduce
+the single-process run of the same scenario, on every rank -- including when only ONE rank's forward
+kernel raises the underflow flag: the redo it triggers contains an all-reduce, so the decision has to
+be the same on all ranks (the flags ride in the step's all-reduce; round-1 decided rank-locally and
+would pair the collectives of different iterations).  Replaces the reference's thread fan-out
+(src/phlash/gpu.py:386-438)."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "mr_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, out, shard, scenario, timeout=600):
+    port = str(_free_port())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, out, shard, scenario], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # the exact PIDs this test started
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} of {world} ({shard}, {scenario}) failed:\n{logs[r][-3000:]}"
+    return [torch.load(f"{out}.rank{r}.pt") for r in range(world)]
+
+
+@pytest.mark.parametrize("shard,scenario", [("chunks", "plain"), ("particles", "plain"), ("chunks", "real_flag"),
+                                            ("chunks", "fake_flag"), ("particles", "fake_flag")])
+def test_two_ranks_reproduce_one(tmp_path, shard, scenario):
+    one = _launch(1, str(tmp_path / "w1"), shard, scenario)[0]
+    two = _launch(2, str(tmp_path / "w2"), shard, scenario)
+    # float64 kernels (plain): sums are re-associated by the sharding, nothing else; float32 kernels after
+    # the switch to per-site rescaling are per-sequence deterministic as well (no dense hom-run steps)
+    tol = dict(rtol=1e-9, atol=1e-12)
+    for r in range(2):
+        for key in ("c", "t", "rho"):
+            np.testing.assert_allclose(two[r][key], one[key], err_msg=f"rank {r} {key}", **tol)
+        assert torch.isfinite(two[r]["c"]).all()
+    if scenario == "real_flag":
+        # the device flag was raised on rank 1 only (it owns the odd rows, which hold the het runs) ...
+        first = [two[r]["handed"][0] for r in range(2)]
+        assert first[0][0] == 0 and first[1][0] == 1, first
+        # ... and BOTH ranks switched to per-site rescaling, exactly once, like the single process
+        assert two[0]["nrm_calls"] == two[1]["nrm_calls"] == one["nrm_calls"] == [1]
+    if scenario == "fake_flag":
+        assert two[0]["handed"][0][0] == 0 and two[1]["handed"][0][0] == 1
+        assert two[0]["nrm_calls"] == two[1]["nrm_calls"] == [1]
+    if scenario == "plain":
+        assert two[0]["nrm_calls"] == two[1]["nrm_calls"] == []
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    """bench.py's own step (param map -> kernels -> all-reduce -> chain rule -> SVGD) with two ranks on
+    the real kernels, tiny shapes; bench.py asserts that the replicated particles are identical on all
+    ranks after the timed loop."""
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+             "--particles", "12", "--chunks", "40", "--chunk-size", "4000", "--no-cpu-baseline"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][1][-3000:]
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert outs[1][0].strip() == ""  # only rank 0 prints

@@ -32,7 +32,7 @@ class _OracleKern:
         from oracle import cport
 
         P = pp.stack().numpy()[:, None]
-        ll, g = cport.batch(P, self.rows, inds.numpy(), self.overlap, nthreads=2)
+        ll, g = cport.batch(P, self.rows, np.asarray(inds), self.overlap, nthreads=2)
         return torch.tensor(ll.sum(1)), torch.tensor(g.sum(1))
 
 

@@ -1,0 +1,211 @@
+"""GPU tests of what round 2 added around the kernels: every compiled template instantiation once
+against the oracle, the no-gradient ELPD path, the deterministic mode, the device-side index check and
+the stream-ordered flag hand-over."""
+
+import numpy as np
+import pytest
+
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _params(K, B, seed):
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import particle_population
+
+    tmpl, x = particle_population(K, B, seed=seed, sigma=0.3)
+    return PSMCParams.from_dm(tmpl.from_flat(x).to_dm()).stack()[:, None]  # [B, 1, 7, K]
+
+
+def _valid_R(K, R):
+    return R <= K and K % R == 0 and K // R <= 16
+
+
+@pytest.mark.parametrize("dbl", [False, True])
+@pytest.mark.parametrize("K", [4, 8, 16, 32, 64])
+def test_every_compiled_instantiation_once(K, dbl):
+    """Every (dtype, K, R, T, NRM) instantiation of fwd_kernel<CKPT = false / true>, bwd_kernel<SEG = false /
+    true> and bscan_kernel that the library dispatches to, once each, at L = 4,203 sites (>= 4,096: eight
+    whole segments and a ragged tail; warm-up boundary inside a block), against the float64 oracle.  A
+    miscompiled instantiation (round 1 fenced off two without a diagnosis) cannot hide behind the
+    variants the tuner happens to pick."""
+    from phlash_amd.engine import HipEngine
+    from phlash_amd.synth import simulate_chunks
+
+    L, W, B, S = 4203, 101, 2, 6
+    data = simulate_chunks(K, S, L, seed=K)
+    P = _params(K, B, seed=K + 1)
+    inds = np.arange(S)
+    ll_ref, g_ref = cport.batch(P.numpy(), data, inds, W)
+    scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
+    eng = HipEngine(K, data, double_precision=dbl)
+    eng.set_autotune(False)
+    Pd, di = P.cuda(), torch.arange(S, device="cuda")
+    lt, gt = (1e-10, 1e-8) if dbl else (1e-5, 3e-4)
+    n = 0
+    worst = 0.0
+    for R in (1, 2, 4, 8, 16):
+        if not _valid_R(K, R):
+            continue
+        for T in (8, 16):
+            if T == 16 and K // R > 4:
+                continue
+            bwd_ok = not (dbl and K // R > 8)  # float64 with 16 states per lane: forward variant only
+            Rb = R if bwd_ok else R * 2
+            for nrm in (1, 2, 4):
+                eng.set_rescale_interval(nrm)
+                tag = f"K={K} {'f64' if dbl else 'f32'} R={R} T={T} nrm={nrm}"
+                # fwd_kernel<CKPT = false>
+                eng.set_plan(0, R=Rb, T=T, R_forward=R, R_scan=0)
+                ll0 = eng.run(Pd, di, W, grad=False).cpu().numpy()
+                np.testing.assert_allclose(ll0, ll_ref, rtol=lt, err_msg=tag + " no-grad")
+                # fwd_kernel<CKPT = true> (variant R) + bwd_kernel<SEG = false> (variant Rb)
+                ll1, g1 = eng.run(Pd, di, W, grad=True)
+                np.testing.assert_allclose(ll1.cpu().numpy(), ll_ref, rtol=lt, err_msg=tag + " serial")
+                e1 = (np.abs(g1.double().cpu().numpy() - g_ref) / scale).max()
+                assert e1 < gt, (tag + " serial", e1)
+                # bscan_kernel (variant R) + fwd_kernel<CKPT = true> + bwd_kernel<SEG = true> (variant Rb) + finalize
+                eng.set_plan(1, R=Rb, T=T, R_forward=R, R_scan=R)
+                ll2, g2 = eng.run(Pd, di, W, grad=True)
+                np.testing.assert_allclose(ll2.cpu().numpy(), ll_ref, rtol=lt, err_msg=tag + " segmented")
+                e2 = (np.abs(g2.double().cpu().numpy() - g_ref) / scale).max()
+                assert e2 < gt, (tag + " segmented", e2)
+                worst = max(worst, e1, e2)
+                n += 1
+    print(f"K={K} {'f64' if dbl else 'f32'}: {n} (R, T, NRM) combinations x 3 launch forms, worst gradient error {worst:.2e}")
+    assert n >= 3
+
+
+def test_elpd_path_runs_the_forward_kernel_only():
+    """mcmc.py:224-238 evaluates the held-out log density without a gradient; the reference's primal
+    rule then runs the no-gradient kernel (gpu.py:446-449).  Here: autograd off -> sharded_loglik_sum ->
+    PSMCKernel.value: no checkpoint store is allocated, no backward kernel runs, and the device time
+    is the forward kernel's."""
+    from phlash_amd import parallel
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import simulate_chunks
+
+    K, B, S, L, W = 16, 32, 64, 20_000, 1
+    data = simulate_chunks(K, S, L, seed=2)
+    pp = PSMCParams.unstack(_params(K, B, seed=3)[:, 0].cuda())
+    inds = np.arange(S)
+    kern = get_kernel(K, data, False, overlap=W)
+    kern._eng.set_profiling(True)
+    with torch.no_grad():
+        for _ in range(2):
+            v = parallel.sharded_loglik_sum(kern, pp, inds)
+    f0, b0, n0 = kern._eng.last_timing()
+    assert kern._eng.workspace_bytes() == 0, "the no-gradient path must not allocate the checkpoint store"
+    assert b0 < 0.05 * f0 + 0.02, (f0, b0)  # nothing between the mid and the end event
+    assert not kern.check_rescaling(collective=True)
+    # the same quantity with the gradient (forward + checkpoints + backward)
+    stacked = pp.stack().requires_grad_(True)
+    for _ in range(2):
+        v2 = parallel.sharded_loglik_sum(kern, PSMCParams.unstack(stacked), inds)
+    f1, b1, _ = kern._eng.last_timing()
+    np.testing.assert_allclose(v.cpu(), v2.detach().cpu(), rtol=1e-6)
+    print(f"ELPD path {f0 + b0:.2f} ms (forward only) vs gradient path {f1:.2f} + {b1:.2f} ms")
+    assert f0 + b0 < 0.6 * (f1 + b1)
+    assert kern._eng.workspace_bytes() > 0
+
+
+def test_deterministic_mode_is_bit_reproducible(monkeypatch):
+    """PHK_DETERMINISTIC / phk_set_deterministic: static plan and fixed-order reductions.  The segment
+    sweep used to add its partial sums with float64 atomics (order = arrival order); now every unit
+    stores its sums in a slot of its own and the finalize kernel adds them in unit order, so hybrid and
+    segmented plans return the same bits on every call."""
+    from phlash_amd.engine import HipEngine
+    from phlash_amd.synth import simulate_chunks
+
+    K, B, S, L, W = 16, 24, 50, 20_000, 500
+    data = simulate_chunks(K, S, L, seed=4)
+    P = _params(K, B, seed=5).cuda()
+    di = torch.arange(S, device="cuda")
+    for form in ("segmented", "hybrid"):
+        eng = HipEngine(K, data, False)
+        eng.set_autotune(False)
+        if form == "segmented":
+            eng.set_plan(1, R=4, T=8, R_forward=16, R_scan=4)
+        else:
+            monkeypatch.setenv("PHK_HYBRID", "2:1:640:4:2")
+        runs = [eng.run(P, di, W, grad=True) for _ in range(3)]
+        monkeypatch.delenv("PHK_HYBRID", raising=False)
+        for ll, g in runs[1:]:
+            assert torch.equal(ll, runs[0][0]) and torch.equal(g, runs[0][1]), form
+    # the whole sampler: two runs with one key are identical to the last bit
+    from phlash_amd.data import RawContig
+    from phlash_amd.mcmc import fit
+
+    rng = np.random.default_rng(0)
+    contigs = [RawContig(het_matrix=(rng.uniform(size=(1, 9000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
+               for _ in range(3)]
+    kw = dict(key=11, niter=6, overlap=100, chunk_size=2900, num_particles=40, minibatch_size=3, progress=False,
+              deterministic=True)
+    a, b = fit(contigs, **kw), fit(contigs, **kw)
+    for x, y in zip(a, b):
+        assert torch.equal(x.eta.c, y.eta.c) and x.rho == y.rho
+    # and the environment switch reaches the handle
+    monkeypatch.setenv("PHK_DETERMINISTIC", "1")
+    eng = HipEngine(K, data, False)
+    r1 = eng.run(P, di, W, grad=True)
+    r2 = eng.run(P, di, W, grad=True)
+    assert torch.equal(r1[1], r2[1])
+
+
+def test_out_of_range_chunk_index():
+    """gpu.py:197-199 asserts 0 <= index < N on the host.  Host indices are checked the same way; indices
+    that live on the device are checked by the kernels (clamped to row 0, sticky flag) and reported at
+    the next flag query instead of reading out of bounds."""
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import simulate_chunks
+
+    K, S, L = 16, 5, 300
+    data = simulate_chunks(K, S, L, seed=6)
+    kern = get_kernel(K, data, False)
+    pp = PSMCParams.unstack(_params(K, 3, seed=7)[:, 0].cuda())
+    with pytest.raises(AssertionError):
+        kern.value_and_grad(pp, np.array([0, S]))
+    with pytest.raises(AssertionError):
+        kern.value(pp, np.array([-1]))
+    bad = torch.tensor([0, 4, S + 100], device="cuda")
+    ll, g = kern.value_and_grad(pp, bad)  # no fault: the row is clamped
+    assert torch.isfinite(ll).all()
+    with pytest.raises(AssertionError, match="outside"):
+        kern.check_rescaling()
+    assert not kern.check_rescaling()  # reported once, then clear
+    # ... and through the all-reduce buffer (the multi-rank path)
+    kern.value(pp, torch.tensor([S], device="cuda"))
+    dst = torch.zeros(2, dtype=torch.float64, device="cuda")
+    kern.take_flags_into(dst)
+    with pytest.raises(AssertionError, match="outside"):
+        kern.check_rescaling(collective=True)
+    ok = kern.value(pp, torch.arange(S, device="cuda"))
+    kern.take_flags_into(dst)
+    assert not kern.check_rescaling(collective=True) and torch.isfinite(ok).all()
+
+
+def test_flag_is_read_behind_the_launch_stream():
+    """phk_underflow_risk on a non-default stream: PyTorch's pool streams are non-blocking, so a read on
+    the null stream would not wait for the forward kernel.  The query now goes through the
+    stream of the last launch."""
+    from phlash_amd.engine import HipEngine
+
+    K = 16
+    P = _params(K, 1, seed=0)
+    P[0, 0, 5] = 1e-11
+    P[0, 0, 4] = 1.0 - 1e-11
+    data = np.zeros((64, 30_000), dtype=np.int8)
+    data[:, 20_000:20_064] = 1  # the underflow happens late in a long row
+    eng = HipEngine(K, data, False)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        Pd, di = P.cuda().expand(256, 1, 7, K).contiguous(), torch.arange(64, device="cuda")
+        side.synchronize()
+        eng.run(Pd, di, 0, grad=False)
+        assert eng.underflow_risk()  # must wait for the kernel on `side`
+        assert not eng.underflow_risk()
