@@ -18,6 +18,12 @@ from oracle import cport
 
 pytestmark = pytest.mark.gpu
 
+# float32: largest difference between two kernel variants over every row of the 12 x 500 sequences of the
+# cfg2-shaped batch (row-scaled; pi row pi-weighted).  Measured: 2.1e-3 (the worst of 36,000 rows; the oracle
+# sample sits at 2e-5) and 2.7e-4; what SVGD consumes is bounded in test_cfg2_f32_gradient_in_particle_space.
+F32_VARIANT_ROWS = 5e-3
+F32_VARIANT_PI = 1e-3
+
 torch = pytest.importorskip("torch")
 
 
@@ -79,15 +85,45 @@ def test_cfg2_properties(dbl):
         eng.set_rescale_interval(nrm)
         ll2, g2 = eng.run(P, inds, W, grad=True)
         np.testing.assert_allclose(ll2.cpu(), ll.cpu(), rtol=1e-11 if dbl else 2e-6, atol=0 if dbl else 2e-3)  # see above
+        # rows b, d, u, v, e0, e1 against the row's own maximum (floor 1); the pi row in the form the
+        # reference kernel returns, pi_i * d ll / d pi_i (gpu.py:303-313), whose natural scale is 1
         gs = g.double().abs().amax(-1, keepdim=True).clamp_min(1.0)
         err = (g2.double() - g.double()).abs() / gs
-        # f32: every variant sits ~6e-4 (worst element 2e-3) from the f64 oracle for the same reason -- the
-        # parameter block itself is rounded to f32 (d_j = 1 - O(1e-5) keeps 3 digits of 1 - d_j) and 60,000
-        # sites amplify that; two variants may therefore differ by twice that in their worst element
-        assert float(err[..., :6, :].max()) < (1e-8 if dbl else 5e-3)
-        # pi row with a warm-up prefix: a difference of two nearly equal sweeps (see test_hip_parity._check),
-        # in f32 it carries absolute noise of order 1e-2 whatever the variant
-        assert float(err[..., 6, :].max()) < (1e-8 if dbl else 5e-2)
+        e_rows = float(err[..., :6, :].max())
+        e_pi = float(((g2.double() - g.double())[..., 6, :] * P[..., 6, :].double()).abs().max())
+        print(f"cfg2 {'f64' if dbl else 'f32'} variant R={R} nrm={nrm} vs the tuner's plan: rows {e_rows:.2e}, pi row (pi-weighted) {e_pi:.2e}")
+        # float32: both variants carry the round-off of 60,000 dependent steps; against the float64
+        # oracle each sits at <= 2e-5 row-scaled on these rows (sample above), so two variants differ by
+        # at most a few times that
+        assert e_rows < (1e-8 if dbl else F32_VARIANT_ROWS)
+        assert e_pi < (1e-8 if dbl else F32_VARIANT_PI)
+
+
+def test_cfg2_f32_gradient_in_particle_space():
+    """The float32 gradient where it is consumed: the [B, D] particle-space gradient of the summed
+    log-likelihood over the WHOLE cfg2 batch (100 x 500 x 60,000 + 500), float32 kernels against float64
+    kernels, per particle |g32 - g64| / |g64|.  Bar: <= 1e-3 for every particle, and -- on a bounded
+    sample both can run (all particles x 8 chunks, no warm-up) -- no worse than the reference's OWN float32
+    kernel is against its float64 kernel on identical inputs (oracle/_ref, gpu.py:575-692 compiled
+    unmodified).  Measured (profiles/r02a_bench_cfg2.json): ours 2.3e-4 max / 3.4e-5 median on the full
+    batch; on the sample ours 1.8e-4 / 2.7e-5, the reference's float32 kernel 5.2e-4 / 5.7e-5."""
+    import bench
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.synth import particle_population, simulate_chunks
+
+    K, B, S, L, W = 16, 100, 500, 60_000, 500
+    data = simulate_chunks(K, S, W + L, seed=1000)
+    tmpl, x0 = particle_population(K, B, seed=1)
+    dev = torch.device("cuda", 0)
+    kern = get_kernel(K, data, double_precision=False, overlap=W)
+    r = bench.gradient_parity_leg(tmpl, x0, data, W, dev, kern)
+    print(r)
+    assert r["ours_f32_vs_ours_f64_full_batch"]["max"] < 1e-3
+    assert r["ours_f64_vs_oracle_sample"]["max"] < 1e-9
+    if "reference_f32_vs_reference_f64_sample" in r:
+        ours, ref = r["ours_f32_vs_ours_f64_sample"], r["reference_f32_vs_reference_f64_sample"]
+        assert ours["max"] <= ref["max"] and ours["median"] <= ref["median"], (ours, ref)
+        assert r["ours_f64_vs_reference_f64_sample"]["max"] < 1e-9
 
 
 def test_cfg2_posterior_identities():

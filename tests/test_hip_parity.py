@@ -4,6 +4,8 @@ north-star bar of 1e-5 relative on the log-likelihood (BASELINE.json) and 2e-3 o
 gradients (the reference's own tests accept 1e-3..1e-2: tests/test_model.py:17-19,
 tests/test_gpu.py:29-31)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -61,6 +63,14 @@ def _check(ll, g, ll_ref, g_ref, dbl):
         err = np.abs(g - g_ref) / scale
         assert err.max() < gtol, f"gradient error {err.max():.3e} (row-scaled) >= {gtol}"
 
+
+# Gradient bars of the random-shape test, per row: |error| <= OWN * max|row| + FULL * max|W = 0 row|.
+# Set from the measured distribution over 2,000 draws (profiles/r02_f32_gradient_bars.txt): float32 worst
+# W = 0 draw 1.9e-4 of its row, smallest FULL that passes every draw 2.2e-4; float64 2.8e-13 and 1.1e-11.
+# Both precisions need the FULL term by a similar multiple of their epsilon: it is the conditioning of
+# a difference of two sweeps (see the test), not float32 slack.
+F32_GRAD_OWN, F32_GRAD_FULL = 1e-3, 5e-4
+F64_GRAD_OWN, F64_GRAD_FULL = 1e-9, 5e-11
 
 VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (4, 16), (8, 16), (16, 16)]
 
@@ -360,7 +370,7 @@ def test_tiny_emissions_need_per_site_rescaling():
     assert not e4.underflow_risk()
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PHK_FUZZ_SEEDS", "120"))))
 def test_random_shapes_against_the_oracle(seed):
     """Seeded random draws over everything the launch depends on -- K, float type, particles x
     chunks (shared or per-chunk parameter blocks), row length, warm-up, missing-data rate, plan
@@ -404,8 +414,6 @@ def test_random_shapes_against_the_oracle(seed):
     elif mode == 2:
         eng.set_plan(0, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
     # mode 3: the tuner / static rule decides
-    import os
-
     if hybrid:
         os.environ["PHK_HYBRID"] = hybrid
     try:
@@ -415,29 +423,36 @@ def test_random_shapes_against_the_oracle(seed):
     Pin = P if dbl else P.astype(np.float32).astype(np.float64)
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5, atol=1e-10 if dbl else 1e-5)
-    # Gradient metric.  (1) pi row in the form the reference kernel returns, pi_i * d ll/d pi_i
-    # (gpu.py:303-313): on data far from the model (50 % hets) d ll/d pi_i = P(o | z_0 = i) / P(o)
-    # reaches 1e9 for states of tiny pi_i, and with a warm-up prefix the result is the difference of
-    # two such sweeps; weighted by pi_i it is well conditioned.  (2) With W > 0 every row is the
-    # difference of the gradients of log P(o_1..L) and log P(o_1..W); when the scored part carries
-    # little information (W close to L, scored sites missing) that difference is far smaller than
-    # its two terms and only its size relative to THEM is computable: rows are judged against the
-    # larger of their own maximum and a fraction of the whole-row (W = 0) gradient's maximum --
-    # 1e-6 of it in float64, a tenth of it in float32.
+    # Gradient metric: per row (b, s, parameter row) the largest absolute error against
+    #     bound = a * max|row of the oracle's gradient| + c * max|same row of the W = 0 gradient|.
+    # (1) pi row in the form the reference kernel returns, pi_i * d ll/d pi_i (gpu.py:303-313): on data far
+    # from the model (50 % hets) d ll/d pi_i = P(o | z_0 = i) / P(o) reaches 1e9 for states of tiny pi_i;
+    # weighted by pi_i it is well conditioned, with natural scale sum_i pi_i dll/dpi_i = 1 (W = 0).
+    # (2) The c term is the conditioning of the warm-up form, not slack: with W > 0 every row is the
+    # DIFFERENCE of the gradients of log P(o_1..L) and log P(o_1..W), each computed to a relative accuracy
+    # eps of ITS size; when the scored part carries little information (W close to L, scored sites
+    # missing) the difference is far smaller than its two terms and what any float32 evaluation -- the
+    # reference's JAX warm-up scan plus its float32 kernel included -- can guarantee is eps * |terms|, i.e.
+    # c ~ eps x (steps).  (a, c) are set from the measured distribution over 2,000 draws (F32_GRAD_* / F64_GRAD_* above).
     g, g_ref = g.copy(), g_ref.copy()
     g[..., 6, :] *= P[..., 6, :]
     g_ref[..., 6, :] *= P[..., 6, :]
-    scale = np.abs(g_ref).max(axis=-1, keepdims=True)
+    own = np.abs(g_ref).max(axis=-1, keepdims=True)
+    own[..., 6, :] = np.maximum(own[..., 6, :], 1.0)
+    full = np.zeros_like(own)
     if W > 0:
         _, g_full = cport.batch(Pin, data, inds, 0)
         g_full[..., 6, :] *= P[..., 6, :]
-        scale = np.maximum(scale, (1e-6 if dbl else 0.1) * np.abs(g_full).max(axis=-1, keepdims=True))
-    scale[..., 6, :] = np.maximum(scale[..., 6, :], 1.0)
-    scale = np.maximum(scale, 1e-300)
-    err = (np.abs(g - g_ref) / scale).max()
-    # (float64: 1e-7 here -- two of 2,000 draws, all-hom rows with W ~ L/2, reach 7e-8 in the b row by
-    # conditioning alone; the fixed-input tests keep 1e-8)
-    assert err < (1e-7 if dbl else 5e-3), f"gradient error {err:.3e}"
+        full = np.abs(g_full).max(axis=-1, keepdims=True)
+    err_row = np.abs(g - g_ref).max(axis=-1, keepdims=True)
+    a, c = (F64_GRAD_OWN, F64_GRAD_FULL) if dbl else (F32_GRAD_OWN, F32_GRAD_FULL)
+    bound = a * own + c * full + 1e-300
+    worst = float((err_row / bound).max())
+    r_own = float((err_row / np.maximum(own, 1e-300)).max())
+    r_full = float((err_row / np.maximum(full, 1e-300)).max()) if W > 0 else 0.0
+    print(f"fuzz seed={seed} K={K} {'f64' if dbl else 'f32'} B={B} S={S} L={L} W={W} het={het} mode={mode}: "
+          f"err/own {r_own:.2e} err/full {r_full:.2e} err/bound {worst:.2f}")
+    assert worst < 1.0, f"gradient error {worst:.2f} x its bound ({a:g} x row + {c:g} x whole-row)"
     ll_only = _run(eng, P, inds, W, grad=False)
     np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
 
