@@ -78,8 +78,13 @@ static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t
     }
 }
 // float64 with 16 states per lane: not compiled (288 VGPRs of state vectors alone; see phk_api.hip, valid_Rb)
+#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile the fenced-off variant
+template <int R, int T>
+constexpr bool bwd_variant_ok() { return variant_ok<R, T>(); }
+#else
 template <int R, int T>
 constexpr bool bwd_variant_ok() { return variant_ok<R, T>() && (sizeof(real_t) == 4 || KK / R <= 8); }
+#endif
 
 template <int R, int T>
 static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t st) {

@@ -170,7 +170,11 @@ bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R
 // The backward kernel keeps T + 1 state vectors of K/R reals per lane in registers.  In float64 with
 // 16 states per lane that is 288 VGPRs for them alone: the instantiation spills 1.6 KB per thread, is
 // never the fastest, and one build of it returned a corrupted gradient element -- it is not compiled.
+#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py)
+bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R); }
+#else
 bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8); }
+#endif
 // T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
 bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
 size_t real_size(const phk_handle* h) { return h->dbl ? 8 : 4; }

@@ -39,6 +39,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PHK_EXP_LAND_F64
+#define PHK_EXP_LAND_F64 0  // diagnostic builds only: 1 applies the float32 kernels' piece-landing asm to float64 too
+#endif
+// A/B switches of scripts/ab_build.sh (defaults = the shipped behaviour)
+#ifndef PHK_SERIAL_PRIO
+#define PHK_SERIAL_PRIO 0  // s_setprio of the serial backward sweep's waves (0..3)
+#endif
+#ifndef PHK_FWD_SITE_BARRIER
+#define PHK_FWD_SITE_BARRIER 1  // scheduling barrier after every site of the forward kernel's straight-line block
+#endif
+
 namespace phk {
 
 constexpr int NT_MAX = 256;        // max threads per workgroup (4 waves); the launch picks <= this
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     // checkpoint stores.  float32 kernels only: the float64 K = 64 forward kernel (pieces and
     // parameters loaded straight into AGPRs, scratch in use) returned wrong log-likelihoods with it,
     // in this form and with an explicit s_waitcnt alike, and passes without.
-    if constexpr (sizeof(real) == 4) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));
+    if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));
     int blk = 0;
     for (int pc = 0; blk < nblk; ++pc) {
       const uint4 pcur = pnext;
@@ -806,7 +817,9 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
 #pragma unroll
                     for (int h = 0; h < NP; ++h) ec[h] = en[h];
                 }
+#if PHK_FWD_SITE_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         } else {
 #pragma unroll
@@ -850,8 +863,14 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
 // no LDS block store and no address arithmetic; LDS holds only the emission table.
 // ---------------------------------------------------------------------------------------------
 // waves per SIMD the backward kernel is compiled for: 2 where T*SPL alphas + state fit 256 VGPRs
-template <typename real, int K, int R, int T>
-constexpr int bwd_waves_per_simd() { return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1; }
+#ifndef PHK_SEG_WAVES
+#define PHK_SEG_WAVES 0  // A/B: waves per SIMD the segment sweep is compiled for where it owns <= 4 states per lane (0: as the serial sweep)
+#endif
+template <typename real, int K, int R, int T, bool SEG = false>
+constexpr int bwd_waves_per_simd() {
+    if (SEG && PHK_SEG_WAVES > 0 && T == 8 && (K / R) * (int)sizeof(real) <= 16) return PHK_SEG_WAVES;
+    return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1;
+}
 
 // SEG = false: one unit per sequence sweeps all blocks (blockIdx.y == 0) and writes the gradient.
 // SEG = true : blockIdx.y picks a unit of A.seg_blocks blocks; it starts from the beta-scan's value
@@ -860,13 +879,16 @@ constexpr int bwd_waves_per_simd() { return (T * (K / R) * (int)sizeof(real) <= 
 //   depend on the order the units ran in), and grad_finalize_kernel writes the gradient.  Unit 0 also covers every segment up to the one holding the warm-up
 //   boundary (the correction there makes those segments depend on each other).
 template <typename real, int K, int R, int T, int NRM, bool SEG>
-__global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void bwd_kernel(KArgs A) {
+__global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>())) void bwd_kernel(KArgs A) {
     using L = Lane<real, K, R>;
     using V = typename L::V;
     constexpr int SPL = L::SPL, NP = L::NP;
     static_assert(T <= 16 && 16 % T == 0 && T % NRM == 0, "block / rescale schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
+#if PHK_SERIAL_PRIO
+    if constexpr (!SEG) __builtin_amdgcn_s_setprio(PHK_SERIAL_PRIO);
+#endif
     const int64_t nseq = A.B * A.S;
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
     const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + tid / R;
@@ -970,7 +992,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T>())) void
         }
         const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
         const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        if (bwd_straight_line<real, K, R, T>() && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
+        if (bwd_straight_line<real, K, R, T>() && bwd_waves_per_simd<real, K, R, T, SEG>() <= 2 && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
             // full block, no warm-up boundary inside: straight-line code for all 2T site steps.
             // re-run the block forward (bit-identical to kernel 1), keeping every alpha; the
             // emission row of the NEXT step is always in flight while the current one computes,
@@ -1186,7 +1208,7 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     int w = nw - 1;
     int pc = w >> 2;
     uint4 pnext = pieces[pc > 0 ? pc : 0];
-    if constexpr (sizeof(real) == 4) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
+    if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
     for (; w >= 0; --pc) {
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];

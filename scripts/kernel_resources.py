@@ -22,7 +22,7 @@ def main():
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], {}
     for line in err.splitlines():
-        m = re.search(r"remark: (?:\[[^\]]*\] )?\s*([A-Za-z ]+): (.+?) \[-Rpass", line)
+        m = re.search(r"remark:\s+([^:]+): (.+?) \[-Rpass", line)
         if not m:
             continue
         key, val = m.group(1).strip(), m.group(2).strip()
@@ -33,7 +33,7 @@ def main():
             cur[key] = val
     print(f"{'kernel':58s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'LDS':>6s}")
     for r in rows:
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", r["name"]], capture_output=True, text=True).stdout.strip()
+        name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
         name = name.replace("phk::", "").replace("(phk::KArgs)", "").replace("void ", "")
         print(f"{name[:58]:58s} {r.get('VGPRs', '?'):>5s} {r.get('AGPRs', '?'):>5s} "
               f"{r.get('ScratchSize [bytes/lane]', '?'):>8s} {r.get('Occupancy [waves/SIMD]', '?'):>4s} "

@@ -1,25 +1,30 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of the bench command.
-# Usage: scripts/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
-# Counters are collected in their own passes, never together with tracing domains.
+# Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats (+ PMC passes) of the bench command.
+# Usage: scripts/profile.sh <tag> <trace|full> [bench args...]   -> gpurun_out/prof_<tag>/
+# Counters are collected in their own passes, never together with tracing domains.  The PMC passes run
+# with PHK_DETERMINISTIC=1 (static plan, no tuner launches), so that every dispatch of a kernel name is
+# the same launch and the per-dispatch averages are per-launch figures of the bench loop.
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; MODE=${2:-trace}; shift 2 || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# the tuner runs (a few extra launches of every candidate at the start of each pass)
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_$C.log" 2>&1
-done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_SQ" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_SQ2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ2.log" 2>&1
+if [ "$MODE" = full ]; then
+  export PHK_DETERMINISTIC=1
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_$C.log" 2>&1
+  done
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_SQ" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ.log" 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_SQ2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ2.log" 2>&1
+  unset PHK_DETERMINISTIC
+fi
 cd "$REPO"
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 # keep only the small files for the merge back (<= 64 MiB)
 find "$OUT" -name "*.db" -delete
 find "$OUT" -size +8M -delete
-cat "$OUT/summary.txt"
+tail -n 60 "$OUT/summary.txt"
