@@ -46,6 +46,9 @@
 #ifndef PHK_SERIAL_PRIO
 #define PHK_SERIAL_PRIO 0  // s_setprio of the serial backward sweep's waves (0..3)
 #endif
+#ifndef PHK_BSCAN_PRIO
+#define PHK_BSCAN_PRIO 0  // s_setprio of the beta scan's waves (they share SIMDs with the forward kernel's)
+#endif
 #ifndef PHK_FWD_SITE_BARRIER
 #define PHK_FWD_SITE_BARRIER 1  // scheduling barrier after every site of the forward kernel's straight-line block
 #endif
@@ -1163,6 +1166,9 @@ __global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_site
     using V = typename L::V;
     constexpr int SPL = L::SPL, NP = L::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#if PHK_BSCAN_PRIO
+    __builtin_amdgcn_s_setprio(PHK_BSCAN_PRIO);
+#endif
     const int64_t nseq = A.B * A.S;
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
     const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
