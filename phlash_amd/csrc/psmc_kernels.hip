@@ -49,6 +49,12 @@
 #ifndef PHK_BSCAN_PRIO
 #define PHK_BSCAN_PRIO 0  // s_setprio of the beta scan's waves (they share SIMDs with the forward kernel's)
 #endif
+#ifndef PHK_FWD_BIG_PIECES
+#define PHK_FWD_BIG_PIECES 0  // forward kernel with checkpoints: request observation words 256 sites at a time
+#endif
+#ifndef PHK_EMIS_AHEAD
+#define PHK_EMIS_AHEAD 1  // forward kernel: emission rows requested this many sites ahead (1 or 2)
+#endif
 #ifndef PHK_FWD_SITE_BARRIER
 #define PHK_FWD_SITE_BARRIER 1  // scheduling barrier after every site of the forward kernel's straight-line block
 #endif
@@ -742,10 +748,36 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
     // parameters loaded straight into AGPRs, scratch in use) returned wrong log-likelihoods with it,
     // in this form and with an explicit s_waitcnt alike, and passes without.
     if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));
+    // With checkpoint stores in flight, every wait for a requested piece is a wait for ALL stores issued
+    // before it (one store round trip, ~5,000 cycles under the 2 TB/s this kernel writes: 19 % of a lone
+    // wave's cycles at one wait per 64 sites).  The checkpointing variants that have registers to spare
+    // therefore request FOUR pieces (256 sites) at a time and pay that round trip a quarter as often.
+    constexpr int PPB = (PHK_FWD_BIG_PIECES && CKPT && !has_dense<real, K, R>() && SPL * (int)sizeof(real) >= 32) ? 4 : 1;
+    uint4 nx1 = pnext, nx2 = pnext, nx3 = pnext;
+    if constexpr (PPB == 4) {
+        nx1 = pieces[1 < npieces ? 1 : npieces - 1];
+        nx2 = pieces[2 < npieces ? 2 : npieces - 1];
+        nx3 = pieces[3 < npieces ? 3 : npieces - 1];
+        if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64)
+            asm volatile("" ::"v"(nx1.x), "v"(nx1.y), "v"(nx1.z), "v"(nx1.w), "v"(nx2.x), "v"(nx2.y), "v"(nx2.z), "v"(nx2.w),
+                         "v"(nx3.x), "v"(nx3.y), "v"(nx3.z), "v"(nx3.w));
+    }
     int blk = 0;
-    for (int pc = 0; blk < nblk; ++pc) {
-      const uint4 pcur = pnext;
-      pnext = pieces[pc + 1 < npieces ? pc + 1 : npieces - 1];
+    for (int pc = 0; blk < nblk; pc += PPB) {
+     const uint4 c0 = pnext, c1 = nx1, c2 = nx2, c3 = nx3;
+     if constexpr (PPB == 4) {  // one wait for all four: none of them is "maybe in flight" inside the q loop
+         asm volatile("" ::"v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
+                      "v"(c2.x), "v"(c2.y), "v"(c2.z), "v"(c2.w), "v"(c3.x), "v"(c3.y), "v"(c3.z), "v"(c3.w));
+     }
+     pnext = pieces[pc + PPB < npieces ? pc + PPB : npieces - 1];
+     if constexpr (PPB == 4) {
+         nx1 = pieces[pc + 5 < npieces ? pc + 5 : npieces - 1];
+         nx2 = pieces[pc + 6 < npieces ? pc + 6 : npieces - 1];
+         nx3 = pieces[pc + 7 < npieces ? pc + 7 : npieces - 1];
+     }
+#pragma nounroll
+     for (int q = 0; q < PPB && blk < nblk; ++q) {
+      const uint4 pcur = PPB == 1 ? c0 : (q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)));
       const int bend = blk + BPC < nblk ? blk + BPC : nblk;
       for (int bi = 0; blk < bend; ++blk, ++bi) {
         const int tw = (bi * T) & 15;  // first site of the block inside its word
@@ -806,6 +838,22 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
         } else if (full) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
             // the scheduler can lift every emission ds_read to the top and overlap sites
+#if PHK_EMIS_AHEAD == 2
+            // emission rows requested TWO sites ahead (a ring of three; the indices are constants after
+            // unrolling): an LDS round trip is ~300 cycles here, more than the ~280 one site takes
+            V ring[3][NP];
+            lane.emis(codes & 3, ring[0]);
+            lane.emis((codes >> 2) & 3, ring[1]);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (i + 2 < T) lane.emis((codes >> (2 * (i + 2))) & 3, ring[(i + 2) % 3]);
+                real sc;
+                const int ex = lane.fwd_site(a, ring[i % 3], sc, rescale_after<NRM>(i));
+                E += ex;
+                if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             V ec[NP];
             lane.emis(codes & 3, ec);
 #pragma unroll
@@ -824,6 +872,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < T; ++i) {
@@ -846,6 +895,7 @@ __global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
             ebp += nseq;
         }
       }
+     }
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
