@@ -209,12 +209,25 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
     p.T = h->force_T ? h->force_T : 8;
     p.R = h->force_R ? h->force_R : throughput_R(h, nseq, p.T, 1);
     const int64_t units = n_units(h, 8, W);
-    const bool small = nseq * p.R / 64 < 512 && units >= 8;
+    // small batch: even with the most lanes per sequence a serial sweep would not give every SIMD four
+    // waves -- the sweep is then a chain of L dependent sites per wave on a mostly idle chip
+    const bool small = nseq * largest_R(h, 8) / 64 < 4096 && units >= 8;
     p.segmented = h->mode == 1 || (h->mode < 0 && small && !h->force_R && !h->force_T);
     if (p.segmented) {
+        // what the tuner picks for such shapes here: the latency-bound forward kernel and beta scan with
+        // the most lanes per sequence (K = 16 float32: the dense hom-run kernels), the segment sweep with
+        // <= 4 states per lane, where 16-site blocks fit in registers (half the checkpoint traffic)
         p.T = 8;
         p.R1 = p.R2 = h->force_R ? h->force_R : largest_R(h, 8);
         p.R = h->force_R ? h->force_R : throughput_R(h, nseq * units, 8, 2);
+        if (!h->force_R && !h->force_T) {
+            int Rs = std::max(1, h->K / 4);
+            while (Rs > 1 && !valid_Rb(h, Rs)) Rs >>= 1;
+            if (valid_Rb(h, Rs) && valid_T(h->K, Rs, 16) && valid_T(h->K, p.R1, 16)) {
+                p.R = Rs;
+                p.T = 16;
+            }
+        }
         return p;
     }
     if (!h->force_R && !h->force_T && h->mode < 0) {

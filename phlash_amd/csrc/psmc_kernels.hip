@@ -679,8 +679,21 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 // kernel 1: forward pass.  ll per sequence; optionally alpha checkpoints every T sites.
 // LDS: the per-thread emission table only.
 // ---------------------------------------------------------------------------------------------
+// Waves per SIMD the latency-bound (one state per lane, dense hom-run operators) kernels are compiled for.
+// Left to itself the compiler gives them all 512 registers (the float64 construction of the dense
+// operators in the prologue has long live ranges) -- one wave per SIMD, so that the forward kernel and
+// the beta scan of the segmented plan, 625 waves each at the reference's production shape, could not
+// share the 1,024 SIMDs and ran one after the other.  Their loops need fewer than 100 registers.
+// Measured at 500 x 5 x 100,000 (interleaved A/B, profiles/r02_ab_experiments.txt): 1 wave per SIMD 11.8-12.4
+// ms per step, 2 waves 9.3, 4 waves 9.3-9.4; one 100,000-site sequence: 5.56 / 5.33 / 5.60 ms.
+#ifndef PHK_DENSE_WAVES
+#define PHK_DENSE_WAVES 2
+#endif
+template <typename real, int K, int R>
+constexpr int scan_waves_per_simd() { return has_dense<real, K, R>() ? PHK_DENSE_WAVES : 1; }
+
 template <typename real, int K, int R, int T, int NRM, bool CKPT>
-__global__ __launch_bounds__(NT_MAX) void fwd_kernel(KArgs A) {
+__global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void fwd_kernel(KArgs A) {
     using L = Lane<real, K, R>;
     using V = typename L::V;
     constexpr int SPL = L::SPL, NP = L::NP;
@@ -1211,7 +1224,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 // the segments of a sequence can then be swept in parallel by bwd_kernel<..., SEG = true>.
 // ---------------------------------------------------------------------------------------------
 template <typename real, int K, int R, int NRM>
-__global__ __launch_bounds__(NT_MAX) void bscan_kernel(KArgs A, int64_t seg_sites, void* bseg_out, int32_t* fseg_out) {
+__global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void bscan_kernel(KArgs A, int64_t seg_sites, void* bseg_out, int32_t* fseg_out) {
     using L = Lane<real, K, R>;
     using V = typename L::V;
     constexpr int SPL = L::SPL, NP = L::NP;
