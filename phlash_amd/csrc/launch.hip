@@ -38,17 +38,35 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     return hipGetLastError();
 }
 
+// float64 sweeps that are not compiled (256 VGPRs + AGPR copies + scratch: see phk_api.hip, valid_Rf): the
+// serial sweep with more than 4 states per lane, the segment sweep with more than 8
+#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile every variant
+template <int R, bool SEG>
+constexpr bool f64_sweep_ok() { return true; }
+#else
+template <int R, bool SEG>
+constexpr bool f64_sweep_ok() { return sizeof(real_t) == 4 || KK / R <= (SEG ? 8 : 4); }
+#endif
+
 template <int R, int T, int NRM>
 static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
     const int spb = nt / R;
     const dim3 block(nt);
     if (units <= 0) {  // one serial sweep per sequence
-        const dim3 grid((unsigned)((nseq + spb - 1) / spb));
-        hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds_bytes(R, nt), st, a);
+        if constexpr (f64_sweep_ok<R, false>()) {
+            const dim3 grid((unsigned)((nseq + spb - 1) / spb));
+            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds_bytes(R, nt), st, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
     } else {  // `units` independent segments per sequence
-        const dim3 grid((unsigned)((nseq + spb - 1) / spb), (unsigned)units);
-        hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds_bytes(R, nt), st, a);
+        if constexpr (f64_sweep_ok<R, true>()) {
+            const dim3 grid((unsigned)((nseq + spb - 1) / spb), (unsigned)units);
+            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds_bytes(R, nt), st, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }
@@ -62,9 +80,15 @@ static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_
     return hipGetLastError();
 }
 
-// T = 16 keeps 17 alpha vectors in registers: only offered where a lane owns <= 4 states
+// T = 16 keeps 17 alpha vectors in registers: only offered where a lane owns <= 4 states.  float64 with 16
+// states per lane beyond K = 16: not compiled (more than 256 registers plus scratch: see phk_api.hip, valid_Rf)
+#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile every variant
+constexpr bool f64_fwd_ok(int) { return true; }
+#else
+constexpr bool f64_fwd_ok(int R) { return sizeof(real_t) == 4 || KK / R <= 8 || KK == 16; }
+#endif
 template <int R, int T>
-constexpr bool variant_ok() { return KK % R == 0 && KK / R <= 16 && R <= KK && (T == 8 || KK / R <= 4); }
+constexpr bool variant_ok() { return KK % R == 0 && KK / R <= 16 && R <= KK && (T == 8 || KK / R <= 4) && f64_fwd_ok(R); }
 
 template <int R, int T>
 static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
@@ -77,14 +101,9 @@ static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t
         return hipErrorInvalidValue;
     }
 }
-// float64 with 16 states per lane: not compiled (288 VGPRs of state vectors alone; see phk_api.hip, valid_Rb)
-#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile the fenced-off variant
+// float64 with more than 4 states per lane: not compiled (256 VGPRs + AGPR copies + scratch; see phk_api.hip, valid_Rb)
 template <int R, int T>
-constexpr bool bwd_variant_ok() { return variant_ok<R, T>(); }
-#else
-template <int R, int T>
-constexpr bool bwd_variant_ok() { return variant_ok<R, T>() && (sizeof(real_t) == 4 || KK / R <= 8); }
-#endif
+constexpr bool bwd_variant_ok() { return variant_ok<R, T>() && (f64_sweep_ok<R, false>() || f64_sweep_ok<R, true>()); }
 
 template <int R, int T>
 static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t st) {

@@ -167,13 +167,31 @@ bool pick_launchers(const phk_handle* h, Launchers* l) {
 }
 
 bool valid_R(int K, int R) { return R >= 1 && R <= 16 && (R & (R - 1)) == 0 && R <= K && K % R == 0 && K / R <= 16; }
+// Variants that are not compiled (launch.hip mirrors these rules).  float64 kernels whose lanes own many
+// states need more than 256 registers; hipcc (ROCm 7.2.0) then keeps part of the state in AGPR copies AND
+// in scratch, and in that regime it has produced wrong code: fwd_kernel<double, 64, 4, 8, 2, true> reloaded
+// only the low half of a split 64-bit spill ("A register-allocation miscompile").
+// Kernels that combine AGPR copies with scratch are therefore not shipped (tests/test_layout.py checks
+// the build's resource log): float64 forward / scan variants with 16 states per lane beyond K = 16, and
+// float64 sweeps with more than 4 states per lane.
+#ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py)
+bool valid_Rf(const phk_handle* h, int R) { return valid_R(h->K, R); }
+#else
+bool valid_Rf(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8 || h->K == 16); }
+#endif
 // The backward kernel keeps T + 1 state vectors of K/R reals per lane in registers.  In float64 with
-// 16 states per lane that is 288 VGPRs for them alone: the instantiation spills 1.6 KB per thread, is
-// never the fastest, and one build of it returned a corrupted gradient element -- it is not compiled.
+// 16 states per lane that is 288 VGPRs for them alone (1.6 KB of scratch on top), with 8 states per lane
+// 256 VGPRs + 256 AGPR copies + scratch: never the fastest, and in the regime described above.
 #ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py)
 bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R); }
 #else
-bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8); }
+bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 4); }
+#endif
+// ... as the segment sweep (SEG = true instantiations: no scratch up to 8 states per lane in float64)
+#ifdef PHK_EXP_F64_SPL16
+bool valid_Rs(const phk_handle* h, int R) { return valid_R(h->K, R); }
+#else
+bool valid_Rs(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8); }
 #endif
 // T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
 bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }
@@ -192,7 +210,7 @@ int throughput_R(const phk_handle* h, int64_t units, int T, int waves) {
 int largest_R(const phk_handle* h, int T) {
     int best = 1;
     for (int c = 1; c <= 16; c <<= 1)
-        if (valid_R(h->K, c) && valid_T(h->K, c, T)) best = c;
+        if (valid_Rf(h, c) && valid_T(h->K, c, T)) best = c;
     return best;
 }
 
@@ -235,11 +253,11 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         // forward kernel with half the lanes per sequence of the sweep (its waves are alone on their
         // SIMDs either way, and fewer lanes mean fewer instructions per site), and the sequences
         // beyond whole rounds of 1,024 waves swept by segments (hybrid, see Plan).
-        if (p.R >= 2 && valid_R(h->K, p.R / 2) && nseq * (p.R / 2) / 64 >= 512) p.R1 = p.R / 2;
+        if (p.R >= 2 && valid_Rf(h, p.R / 2) && nseq * (p.R / 2) / 64 >= 512) p.R1 = p.R / 2;
         const int64_t per_round = 1024 * (int64_t)(64 / p.R);
         const int64_t first = (nseq / per_round) * per_round;
-        if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rb(h, 4) &&
-            valid_T(h->K, 4, 8) && valid_R(h->K, 2)) {
+        if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, 4) &&
+            valid_T(h->K, 4, 8) && valid_Rf(h, 2)) {
             p.hybrid_first = first;
             p.R3 = 4;
             p.R2 = 2;
@@ -429,7 +447,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         int bf = 0, bb = 0;
         float tf = 0.f, tb = 0.f;
         for (int R = 1; R <= 16; R <<= 1) {
-            if (!valid_R(K, R) || !valid_T(K, R, T)) continue;
+            if (!valid_Rf(h, R) || !valid_T(K, R, T)) continue;
             float ms = 0.f;
             if ((rc = time_launch([&] { return l.fwd(R, T, h->nrm, want_grad, at, 256, st); }, &ms)) != PHK_OK) return rc;
             if (!bf || ms < tf) { tf = ms; bf = R; }
@@ -465,7 +483,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             float hbest = 0.f;
             const int cand[3][2] = {{4, 2}, {2, 2}, {4, 4}};  // (segment sweep, beta scan) lanes per sequence
             for (const auto& c : cand) {
-                if (!valid_Rb(h, c[0]) || !valid_T(K, c[0], 8) || !valid_R(K, c[1])) continue;
+                if (!valid_Rs(h, c[0]) || !valid_T(K, c[0], 8) || !valid_Rf(h, c[1])) continue;
                 Plan hyb = best;
                 hyb.hybrid_first = first;
                 hyb.R3 = c[0];
@@ -493,7 +511,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             float t[2] = {0.f, 0.f};
             out[0] = out[1] = 0;
             for (int R = 1; R <= 16; R <<= 1) {
-                if (!valid_R(K, R) || (T && !valid_T(K, R, T))) continue;
+                if (!valid_Rf(h, R) || (T && !valid_T(K, R, T))) continue;
                 float ms = 0.f;
                 int r = time_launch([&] { return launch_R(R); }, &ms);
                 if (r != PHK_OK) return r;
@@ -519,7 +537,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             Plan tbest;
             float tbest_ms = 0.f;
             for (int R = 1; R <= 8; R <<= 1) {
-                if (!valid_Rb(h, R) || !valid_T(K, R, T)) continue;
+                if (!valid_Rs(h, R) || !valid_T(K, R, T)) continue;
                 Plan cand;
                 cand.segmented = 1;
                 cand.T = T;
@@ -672,7 +690,7 @@ int phk_destroy(phk_handle* h) {
 int phk_set_variant(phk_handle* h, int R, int T) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (R != 0 && !valid_R(h->K, R)) return fail(PHK_EINVAL, "R=%d invalid for K=%d", R, h->K);
-    if (R != 0 && !valid_Rb(h, R)) return fail(PHK_EINVAL, "R=%d: the float64 backward kernel needs K/R <= 8 (K=%d)", R, h->K);
+    if (R != 0 && !valid_Rb(h, R)) return fail(PHK_EINVAL, "R=%d: the float64 backward kernel needs K/R <= 4 (K=%d)", R, h->K);
     if (T != 0 && T != 8 && T != 16) return fail(PHK_EINVAL, "T must be 0, 8 or 16");
     if (R != 0 && !valid_T(h->K, R, T ? T : 8)) return fail(PHK_EINVAL, "R=%d T=%d not available (T=16 needs K/R <= 4)", R, T);
     h->force_R = R;
@@ -722,9 +740,11 @@ int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int 
     p.T = T;
     p.R1 = R_forward;
     p.R2 = R_scan;
-    if (!valid_Rb(h, p.R) || !valid_T(h->K, p.R, p.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
-    if (p.segmented && (!valid_R(h->K, p.R1) || !valid_R(h->K, p.R2)))
+    if (!(p.segmented ? valid_Rs(h, p.R) : valid_Rb(h, p.R)) || !valid_T(h->K, p.R, p.T))
+        return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", R, p.T, h->K);
+    if (p.segmented && (!valid_Rf(h, p.R1) || !valid_Rf(h, p.R2)))
         return fail(PHK_EINVAL, "segmented plan needs valid R_forward and R_scan (got %d, %d)", R_forward, R_scan);
+    if (!p.segmented && p.R1 != 0 && !valid_Rf(h, p.R1)) return fail(PHK_EINVAL, "R_forward=%d not available for K=%d", R_forward, h->K);
     h->forced_plan = p;
     h->has_forced_plan = 1;
     return PHK_OK;
@@ -794,6 +814,15 @@ int phk_get_slab(phk_handle* h, int64_t* particles, int64_t* chunks) {
     if (chunks) *chunks = h->last_Ss;
     return PHK_OK;
 }
+
+#ifdef PHK_DEBUG_EXPORTS  // diagnostic builds only: the checkpoint store of the last gradient call, copied to the host
+int phk_debug_copy_ckpt(phk_handle* h, void* host, int64_t bytes) {
+    if (!h || !host) return fail(PHK_EINVAL, "NULL argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, h->ckpt.p, (size_t)std::min<int64_t>(bytes, (int64_t)h->ckpt.cap), hipMemcpyDeviceToHost));
+    return PHK_OK;
+}
+#endif
 
 int64_t phk_workspace_bytes(phk_handle* h) {
     return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap + h->part.cap) : 0;
@@ -944,8 +973,11 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         if (rc != PHK_OK) return rc;
     }
     const Plan plan = choose_plan(h, nseq_launch, W, want_grad ? 1 : 0);
-    if (!(want_grad ? valid_Rb(h, plan.R) : valid_R(K, plan.R)) || !valid_T(K, plan.R, plan.T)) return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
-    if (plan.segmented && (!valid_R(K, plan.R1) || !valid_R(K, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
+    if (!(want_grad ? (plan.segmented ? valid_Rs(h, plan.R) : valid_Rb(h, plan.R)) : valid_Rf(h, plan.R)) || !valid_T(K, plan.R, plan.T))
+        return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
+    if (want_grad && !plan.segmented && plan.hybrid_first > 0 && !valid_Rs(h, plan.R3)) return fail(PHK_EINVAL, "segment sweep R=%d not available for K=%d", plan.R3, K);
+    if (plan.segmented && (!valid_Rf(h, plan.R1) || !valid_Rf(h, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
+    if (!plan.segmented && plan.R1 != 0 && !valid_Rf(h, plan.R1)) return fail(PHK_EINVAL, "forward variant R=%d not available for K=%d", plan.R1, K);
     h->last_total = B * S;
     h->last_plan = plan;
     h->last_Bs = std::min(Bs, B);

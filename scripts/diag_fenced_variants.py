@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Diagnostic for the two template instantiations round 1 fenced off after they returned wrong results:
+"""Diagnostic for the float64 instantiations that are not shipped because hipcc has produced wrong code in
+their register regime (more than 256 registers plus scratch):
 
-  (A) bwd_kernel<double, K, R, ...> with K / R = 16 states per lane (one corrupted gradient element per ~30
-      sequences in one build);
-  (B) fwd_kernel<double, 64, ...> with the float32 kernels' piece-landing asm (wrong log-likelihoods).
+  (A) bwd_kernel<double, K, R, ...> with K / R = 8 or 16 states per lane (round 1: one corrupted gradient
+      element per ~30 sequences in one build);
+  (B) fwd_kernel / bscan_kernel<double, K >= 32, ...> with 16 states per lane (round 1: wrong log-likelihoods
+      with the piece-landing asm at K = 64; round 2: fwd_kernel<double, 64, 4, 8, 2, true> wrong after an
+      unrelated restructuring of the piece loop -- root-caused with scripts/diag_f64_k64_fwd.py).
 
 Build a diagnostic library that compiles both in, then run this on the GPU box:
 

@@ -47,6 +47,23 @@ def _run(eng, P, inds, W, grad=True, dlog=False):
     return res.cpu().numpy()
 
 
+def _sweep_R(K, R, dbl):
+    """float64 sweeps own at most 4 states per lane (phk_api.hip, valid_Rb): the nearest variant that exists."""
+    while dbl and K // R > 4:
+        R *= 2
+    return R
+
+
+def _set_variant(eng, K, R, T, dbl):
+    """Variant (R, T) for both kernels where it exists; in float64 with more than 4 states per lane R is a
+    forward variant only and the sweep takes the nearest variant it has."""
+    Rb = _sweep_R(K, R, dbl)
+    if Rb == R:
+        eng.set_variant(R, T)
+    else:
+        eng.set_plan(0, R=Rb, T=T, R_forward=R, R_scan=0)
+
+
 def _check(ll, g, ll_ref, g_ref, dbl):
     if dbl:
         np.testing.assert_allclose(ll, ll_ref, rtol=1e-10, atol=1e-10)
@@ -82,12 +99,12 @@ VARIANTS_16 = [(1, 8), (2, 8), (4, 8), (8, 8), (16, 8), (4, 16), (8, 16), (16, 1
 def test_k16_all_variants(missing_data, R, T, W, nrm, dbl):
     data = missing_data
     eng = _engine(16, data, dbl)
-    if dbl and 16 // R > 8:
-        # the float64 backward kernel is not built for 16 states per lane (phk_api.hip, valid_Rb);
-        # as the forward variant of a plan R = 1 stays available
+    if dbl and 16 // R > 4:
+        # the float64 backward kernel is not built for more than 4 states per lane (phk_api.hip, valid_Rb);
+        # as the forward variant of a plan R = 1 / 2 stay available at K = 16
         with pytest.raises(AssertionError):
             eng.set_variant(R, T)
-        eng.set_plan(0, R=2, T=T, R_forward=R, R_scan=0)
+        eng.set_plan(0, R=4, T=8, R_forward=R, R_scan=0)
     else:
         eng.set_variant(R, T)
     eng.set_rescale_interval(nrm)
@@ -108,8 +125,11 @@ def test_other_K(K, R, dbl, rng):
     data = (rng.uniform(size=(6, 700)) < 0.08).astype(np.int8)
     data.flat[rng.integers(0, data.size, 40)] = -1
     eng = _engine(K, data, dbl)
-    if dbl and K // R > 8:
-        eng.set_plan(0, R=2 * R, T=8, R_forward=R, R_scan=0)  # float64: backward kernel needs K/R <= 8
+    if dbl and K // R > 4:  # float64: sweeps need K/R <= 4, forward kernels K/R <= 8 (or K = 16)
+        Rf = R if (K // R <= 8 or K == 16) else K // 8
+        with pytest.raises(AssertionError):
+            eng.set_variant(R, 8)
+        eng.set_plan(0, R=K // 4, T=8, R_forward=Rf, R_scan=0)
     else:
         eng.set_variant(R, 8)
     P = _params(K, 2, 1, seed=3)
@@ -130,7 +150,7 @@ def test_ragged_lengths(L, rng):
     P = _params(16, 2, 1, seed=1)
     inds = np.arange(3)
     for R, T, nrm in [(2, 8, 1), (4, 8, 4), (16, 16, 2), (8, 8, 2)]:
-        eng.set_variant(R, T)
+        _set_variant(eng, 16, R, T, True)
         eng.set_rescale_interval(nrm)
         for W in sorted({0, min(3, L), L}):
             ll, g = _run(eng, P, inds, W)
@@ -270,7 +290,8 @@ def test_segmented_backward(K, dbl, rng):
     data[:, 0] = 0
     eng = _engine(K, data, dbl)
     eng.set_autotune(False)
-    eng.set_plan(1, R=4 if K == 16 else 8, R_forward=16, R_scan=2 if K == 16 else 4)
+    eng.set_plan(1, R=4 if K == 16 else _sweep_R(K, 8, dbl), R_forward=8 if (dbl and K == 64) else 16,
+                 R_scan=2 if K == 16 else (8 if dbl else 4))
     P = _params(K, 3, 1, seed=5)
     inds = np.array([4, 0, 2, 2])
     for W in (0, 100, 512, 700, L):
@@ -281,7 +302,7 @@ def test_segmented_backward(K, dbl, rng):
         _check(ll, g, ll_ref, g_ref, dbl)
     assert plan["R_forward"] != plan["R"]  # the kernels really ran as different variants
     # checkpoint block 16 (32 blocks per 512-site segment)
-    eng.set_plan(1, R=4 if K == 16 else 16, T=16, R_forward=8 if K == 16 else 16, R_scan=4)
+    eng.set_plan(1, R=4 if K == 16 else 16, T=16, R_forward=8 if K == 16 else 16, R_scan=8 if (dbl and K == 64) else 4)
     for W in (0, 100, 600):
         ll, g = _run(eng, P, inds, W)
         assert eng.get_plan()["T"] == 16
@@ -290,7 +311,7 @@ def test_segmented_backward(K, dbl, rng):
     # same lanes-per-sequence everywhere, every rescale interval, d/dlog output
     eng.set_plan(-1)
     eng.set_backward_mode(1)
-    for R, nrm in ((4, 1), (16, 2)) if K == 16 else ((8, 4),):
+    for R, nrm in ((4, 1), (16, 2)) if K == 16 else ((_sweep_R(K, 8, dbl), 4),):
         eng.set_variant(R, 8)
         eng.set_rescale_interval(nrm)
         ll, g = _run(eng, P, inds, 100, dlog=True)
@@ -401,18 +422,19 @@ def test_random_shapes_against_the_oracle(seed):
     eng = _engine(K, data, dbl)
     eng.set_rescale_interval(int(rng.choice([1, 2, 4])))
     mode = int(rng.integers(5))
-    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]
+    Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]  # forward / scan variants
+    Rsw = [r for r in Rs if K // r <= 4] if dbl else Rs  # serial sweep variants (float64: <= 4 states per lane)
+    Rsg = Rs  # segment sweep variants (float64: <= 8 states per lane)
     hybrid = None
     if mode == 4 and B * S >= 2:  # hybrid form of the serial plan with a random split (developer override)
-        Rb = [r for r in Rs if K // r <= 8] if dbl else Rs
-        hybrid = f"{int(rng.choice(Rb))}:{int(rng.choice(Rs))}:{int(rng.integers(1, B * S))}:{int(rng.choice(Rb))}:{int(rng.choice(Rs))}"
+        hybrid = f"{int(rng.choice(Rsw))}:{int(rng.choice(Rs))}:{int(rng.integers(1, B * S))}:{int(rng.choice(Rsg))}:{int(rng.choice(Rs))}"
     if mode == 0:
-        R = int(rng.choice(Rs))
+        R = int(rng.choice(Rsw))
         eng.set_variant(R, 16 if (K // R <= 4 and rng.integers(2)) else 8)
     elif mode == 1:
-        eng.set_plan(1, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=int(rng.choice(Rs)))
+        eng.set_plan(1, R=int(rng.choice(Rsg)), T=8, R_forward=int(rng.choice(Rs)), R_scan=int(rng.choice(Rs)))
     elif mode == 2:
-        eng.set_plan(0, R=int(rng.choice(Rs)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
+        eng.set_plan(0, R=int(rng.choice(Rsw)), T=8, R_forward=int(rng.choice(Rs)), R_scan=0)
     # mode 3: the tuner / static rule decides
     if hybrid:
         os.environ["PHK_HYBRID"] = hybrid
@@ -604,8 +626,9 @@ def test_hybrid_plan_matches_the_oracle(dbl, rng, monkeypatch):
     inds = np.array([0, 1, 2, 3, 4, 2])  # 18 sequences
     Pin = P if dbl else P.astype(np.float32).astype(np.float64)
     for spec, W in (("2:2:7:4:2", 0), ("2:1:7:2:2", 100), ("4:2:16:4:4", 600), ("2:2:1:2:2", 100), ("2:2:17:4:2", 0)):
-        if dbl and spec.startswith("2:1:"):
-            spec = "2:2:" + spec[4:]
+        if dbl:  # float64: sweeps with <= 4 states per lane, forward variants with <= 8
+            f = spec.split(":")
+            spec = ":".join([str(max(int(f[0]), 4)), str(max(int(f[1]), 2)), f[2], f[3], f[4]])
         monkeypatch.setenv("PHK_HYBRID", spec)
         ll_ref, g_ref = cport.batch(Pin, data, inds, W)
         for _ in range(2):

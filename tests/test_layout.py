@@ -75,3 +75,32 @@ def test_no_fallback_without_gpu():
     data = np.zeros((2, 10), dtype=np.int8)
     with pytest.raises((RuntimeError, ImportError)):
         get_kernel(16, data, False)
+
+
+def test_no_shipped_kernel_mixes_agpr_copies_with_scratch():
+    """hipcc (ROCm 7.2.0) has produced wrong code for a kernel that needed more than 256 registers AND scratch:
+    fwd_kernel<double, 64, 4, 8, 2, true> reloaded only the low half of a split 64-bit spill.
+    Kernels in that regime are excluded from the build (launch.hip variant_ok / bwd_variant_ok); this reads the
+    register / scratch report every translation unit leaves next to its object file and fails if one came back."""
+    import glob
+
+    logs = sorted(glob.glob(os.path.join(ROOT, "phlash_amd", "csrc", "build", "launch_*.o.log")))
+    if len(logs) < 10:
+        pytest.skip("no build logs (the library was not built in this tree)")
+    n, bad = 0, []
+    for f in logs:
+        cur = None
+        for line in open(f):
+            m = re.search(r"remark:\s+([^:]+): (.+?) \[-Rpass", line)
+            if not m:
+                continue
+            k, v = m.group(1).strip(), m.group(2).strip()
+            if k == "Function Name":
+                cur = {"name": v}
+                n += 1
+            elif cur is not None:
+                cur[k] = v
+                if k.startswith("LDS Size") and int(cur.get("AGPRs", "0")) > 0 and int(cur.get("ScratchSize [bytes/lane]", "0")) > 0:
+                    bad.append((os.path.basename(f), cur["name"], cur["AGPRs"], cur["ScratchSize [bytes/lane]"]))
+    assert n >= 500, n
+    assert not bad, bad

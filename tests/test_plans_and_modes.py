@@ -53,8 +53,11 @@ def test_every_compiled_instantiation_once(K, dbl):
         for T in (8, 16):
             if T == 16 and K // R > 4:
                 continue
-            bwd_ok = not (dbl and K // R > 8)  # float64 with 16 states per lane: forward variant only
-            Rb = R if bwd_ok else R * 2
+            if dbl and K // R > 8 and K != 16:
+                continue  # float64 forward / scan variants with 16 states per lane exist at K = 16 only (phk_api.hip, valid_Rf)
+            Rb = R
+            while dbl and K // Rb > 4:  # float64 sweeps own <= 4 states per lane: the variant is then a forward variant only
+                Rb *= 2
             for nrm in (1, 2, 4):
                 eng.set_rescale_interval(nrm)
                 tag = f"K={K} {'f64' if dbl else 'f32'} R={R} T={T} nrm={nrm}"
@@ -67,8 +70,10 @@ def test_every_compiled_instantiation_once(K, dbl):
                 np.testing.assert_allclose(ll1.cpu().numpy(), ll_ref, rtol=lt, err_msg=tag + " serial")
                 e1 = (np.abs(g1.double().cpu().numpy() - g_ref) / scale).max()
                 assert e1 < gt, (tag + " serial", e1)
-                # bscan_kernel (variant R) + fwd_kernel<CKPT = true> + bwd_kernel<SEG = true> (variant Rb) + finalize
-                eng.set_plan(1, R=Rb, T=T, R_forward=R, R_scan=R)
+                # bscan_kernel (variant R) + fwd_kernel<CKPT = true> + bwd_kernel<SEG = true> + finalize (the segment
+                # sweep exists up to 8 states per lane in float64)
+                Rs = R if (not dbl or K // R <= 8) else Rb
+                eng.set_plan(1, R=Rs, T=T, R_forward=R, R_scan=R)
                 ll2, g2 = eng.run(Pd, di, W, grad=True)
                 np.testing.assert_allclose(ll2.cpu().numpy(), ll_ref, rtol=lt, err_msg=tag + " segmented")
                 e2 = (np.abs(g2.double().cpu().numpy() - g_ref) / scale).max()
