@@ -235,10 +235,25 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is reserved for the ONE
+        # JSON line, so file descriptor 1 points at stderr until the communicator exists
+        import ctypes
+
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(a.backend, rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from phlash_amd import parallel, svgd
     from phlash_amd.kernel import get_kernel
