@@ -765,7 +765,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // before it (one store round trip, ~5,000 cycles under the 2 TB/s this kernel writes: 19 % of a lone
     // wave's cycles at one wait per 64 sites).  The checkpointing variants that have registers to spare
     // therefore request FOUR pieces (256 sites) at a time and pay that round trip a quarter as often.
-    constexpr int PPB = (PHK_FWD_BIG_PIECES && CKPT && !has_dense<real, K, R>() && SPL * (int)sizeof(real) >= 32) ? 4 : 1;
+    constexpr int PPB = ((PHK_FWD_BIG_PIECES == 1 && CKPT && !has_dense<real, K, R>() && SPL * (int)sizeof(real) >= 32) ||
+                         (PHK_FWD_BIG_PIECES == 2 && CKPT && has_dense<real, K, R>())) ? 4 : 1;
     uint4 nx1 = pnext, nx2 = pnext, nx3 = pnext;
     if constexpr (PPB == 4) {
         nx1 = pieces[1 < npieces ? 1 : npieces - 1];
