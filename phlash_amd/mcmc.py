@@ -52,6 +52,30 @@ def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, a
     return torch.where(torch.isfinite(ret), ret, torch.full_like(ret, -float("inf")))
 
 
+class _NoRows:
+    """Stands in for the held-out kernel object on a rank that owns none of the held-out rows: it contributes
+    zeros to the all-reduce and reads the (reduced) flags like a real kernel object, so that it takes the same
+    redo branch as its peers, without touching any engine."""
+
+    def __init__(self, device):
+        self.device = device
+        self._flags = None
+
+    def value(self, pp, inds, reduce_chunks: bool = True):  # (never reached: this rank's index list is empty)
+        return torch.zeros(pp.d.shape[0], dtype=F64, device=self.device)
+
+    def take_flags_into(self, dst):
+        self._flags = dst  # nothing of its own to hand over: dst stays zero on this rank
+
+    def check_rescaling(self, collective: bool = False) -> bool:
+        if self._flags is None:
+            return False
+        under, bad = (float(v) for v in self._flags.cpu())
+        self._flags = None
+        assert bad == 0, "a chunk index was out of range on another rank"
+        return under > 0
+
+
 def _join_process_group() -> int:
     """Under torchrun (RANK / WORLD_SIZE in the environment) bind this process to GPU LOCAL_RANK and
     join the process group if the caller has not done so; returns the device ordinal to use.  Without
@@ -185,6 +209,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                                device=device_index) if len(t_mine) else None
         if test_kern is not None and options.get("deterministic"):
             test_kern._eng.set_deterministic(True)
+        no_rows = _NoRows(dev)
         c_elpd = torch.tensor([0.0, 1.0, 1.0], dtype=F64, device=dev)
 
         def elpd_once(xs):
@@ -201,7 +226,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                     parallel.all_reduce_sum_(tot)
                     return tot[0] / xs.shape[0], test_kern
                 if test_kern is None:  # more ranks than test rows: contribute zeros to the all-reduce
-                    k_, li = train_kern, np.zeros(0, np.int64)
+                    k_, li = no_rows, np.zeros(0, np.int64)
                 else:
                     k_, li = test_kern, np.arange(len(t_mine))
                 return _log_density_population(xs, template, c_elpd, k_, li, test_afs, afs_transform).mean(), k_
