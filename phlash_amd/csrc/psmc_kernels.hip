@@ -852,17 +852,18 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         } else if (full) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
             // the scheduler can lift every emission ds_read to the top and overlap sites
-#if PHK_EMIS_AHEAD == 2
-            // emission rows requested TWO sites ahead (a ring of three; the indices are constants after
+#if PHK_EMIS_AHEAD >= 2
+            // emission rows requested PHK_EMIS_AHEAD sites ahead (a ring; the indices are constants after
             // unrolling): an LDS round trip is ~300 cycles here, more than the ~280 one site takes
-            V ring[3][NP];
-            lane.emis(codes & 3, ring[0]);
-            lane.emis((codes >> 2) & 3, ring[1]);
+            constexpr int AH = PHK_EMIS_AHEAD < T ? PHK_EMIS_AHEAD : T - 1;
+            V ring[AH + 1][NP];
+#pragma unroll
+            for (int j = 0; j < AH; ++j) lane.emis((codes >> (2 * j)) & 3, ring[j]);
 #pragma unroll
             for (int i = 0; i < T; ++i) {
-                if (i + 2 < T) lane.emis((codes >> (2 * (i + 2))) & 3, ring[(i + 2) % 3]);
+                if (i + AH < T) lane.emis((codes >> (2 * (i + AH))) & 3, ring[(i + AH) % (AH + 1)]);
                 real sc;
-                const int ex = lane.fwd_site(a, ring[i % 3], sc, rescale_after<NRM>(i));
+                const int ex = lane.fwd_site(a, ring[i % (AH + 1)], sc, rescale_after<NRM>(i));
                 E += ex;
                 if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
                 __builtin_amdgcn_sched_barrier(0);
