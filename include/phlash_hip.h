@@ -90,6 +90,22 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
 int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x,
                   int64_t B, double* params, double* jac, void* stream);
 
+/* The SVGD / AMSGrad update of the sampler's inner step for the whole population on the device:
+ *   phi_j = (1/B) sum_i [ -k_ij g_i + (2/h)(x_i - x_j) k_ij ],  k_ij = exp(-|x_i - x_j|^2 / h);
+ *   AMSGrad (b1, b2, eps, bias correction with `count` = the step number starting at 1, running max of the
+ *   corrected second moment), x_out = x - lr mu_hat / (sqrt(nu_max) + eps);
+ *   h_out = median(pairwise distances of x_out)^2 / log B  (median as torch.quantile(., 0.5)).
+ * Replaces what the reference delegates to blackjax.svgd(..., optax.amsgrad(lr)) per iteration
+ * (src/phlash/mcmc.py:178-199, 279; blackjax 1.2.5 / optax 0.2.6).  All arrays device float64:
+ *   x, grad_logp, mu, nu, nu_max, x_out [B, D] (mu, nu, nu_max updated in place; x_out must not alias x);
+ *   h_in, h_out scalars (may alias); dist_ws workspace of B (B - 1) / 2 doubles, on return the pairwise
+ *   distances of x_out (strict lower triangle).  h_out = NULL skips the median (one workgroup selects it:
+ *   meant for up to a couple of hundred particles; beyond that take the median of dist_ws with a device-wide
+ *   sort).  B <= 4096, D <= 72. */
+int phk_svgd_step(int device, int64_t B, int D, const double* x, const double* grad_logp, double* mu, double* nu,
+                  double* nu_max, const double* h_in, double* h_out, double* x_out, double* dist_ws, int64_t count,
+                  double lr, double b1, double b2, double eps, void* stream);
+
 /* Tuning / introspection (no reference counterpart).
  * R = lanes per sequence (1,2,4,8,16; must divide K, K/R <= 16), T = checkpoint block (8, or 16
  * where K/R <= 4).

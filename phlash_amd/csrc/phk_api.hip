@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <new>
@@ -39,6 +40,22 @@ struct PMArgs {  // must match param_map.hip
     int64_t B;
 };
 hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
+
+constexpr int SV_MAXD = 72, SV_MAXB = 4096;
+struct SVArgs {  // must match svgd_step.hip
+    int64_t B;
+    int D;
+    const double* x;
+    const double* g;
+    double* mu;
+    double* nu;
+    double* nu_max;
+    const double* h_in;
+    double* x_out;
+    double den1, den2;
+    double lr, b1, b2, eps;
+};
+hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hipStream_t st);
 }  // namespace phk
 
 namespace {
@@ -894,6 +911,36 @@ int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, doubl
     HIP_TRY(hipSetDevice(device));
     hipError_t e = phk::launch_param_map(a, (hipStream_t)stream);
     if (e != hipSuccess) return fail(PHK_EHIP, "param_map kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+int phk_svgd_step(int device, int64_t B, int D, const double* x, const double* grad_logp, double* mu, double* nu,
+                  double* nu_max, const double* h_in, double* h_out, double* x_out, double* dist_ws, int64_t count,
+                  double lr, double b1, double b2, double eps, void* stream) {
+    if (!x || !grad_logp || !mu || !nu || !nu_max || !h_in || !x_out || !dist_ws) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 1 || B > phk::SV_MAXB) return fail(PHK_EUNSUPPORTED, "B=%lld particles outside [1, %d]", (long long)B, phk::SV_MAXB);
+    if (D < 1 || D > phk::SV_MAXD) return fail(PHK_EUNSUPPORTED, "D=%d outside [1, %d]", D, phk::SV_MAXD);
+    if (count < 1) return fail(PHK_EINVAL, "count must be >= 1 (the step number, starting at 1)");
+    if (x_out == x) return fail(PHK_EINVAL, "x_out must not alias x (every workgroup reads all particles)");
+    phk::SVArgs a;
+    a.B = B;
+    a.D = D;
+    a.x = x;
+    a.g = grad_logp;
+    a.mu = mu;
+    a.nu = nu;
+    a.nu_max = nu_max;
+    a.h_in = h_in;
+    a.x_out = x_out;
+    a.den1 = 1.0 - std::pow(b1, (double)count);
+    a.den2 = 1.0 - std::pow(b2, (double)count);
+    a.lr = lr;
+    a.b1 = b1;
+    a.b2 = b2;
+    a.eps = eps;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_svgd_step(a, dist_ws, h_out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "svgd step kernels: %s", hipGetErrorString(e));
     return PHK_OK;
 }
 

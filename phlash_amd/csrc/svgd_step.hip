@@ -1,0 +1,262 @@
+// The SVGD / AMSGrad update of the sampler's inner step on the device, in three launches.
+//
+// Reference: jthlab/phlash v1.0.6 src/phlash/mcmc.py:178-199, 279 delegates this to
+// blackjax.svgd(grad(log_density), optax.amsgrad(lr)) (blackjax==1.2.5, optax==0.2.6; sources absent, so
+// the definition this kernel is tested against is the torch restatement in phlash_amd/svgd.py):
+//   k(x_i, x_j) = exp(-|x_i - x_j|^2 / h)
+//   phi_j       = (1/n) sum_i [ -k_ij g_i + (2/h) (x_i - x_j) k_ij ]          (g = grad log p)
+//   AMSGrad     : mu = b1 mu + (1-b1) phi, nu = b2 nu + (1-b2) phi^2, bias-corrected, running max of nu_hat,
+//                 x <- x - lr mu_hat / (sqrt(nu_max) + eps)
+//   h_next      = median(pairwise distances of the new x)^2 / log n   (median = torch.quantile(., 0.5))
+// The torch restatement is ~70 launches of a few microseconds each per step (about 0.4 ms, i.e. 1 % of a cfg2
+// step and 5 % of a step at the reference's production shape); here it is
+//   svgd_update_kernel : one workgroup per particle j: its kernel row k(., x_j) into LDS, then one lane per
+//                        coordinate sums over i in index order and applies the AMSGrad update (float64);
+//   pair_dist_kernel   : the n (n - 1) / 2 pairwise distances of the new particles;
+//   median_kernel      : ONE workgroup: exact bucket select of the two middle order statistics, h_next.  One
+//                        workgroup reads at one CU's rate (~25 GB/s), so this is for populations of up to a
+//                        couple of hundred particles (cfg2: 100 -> 4,950 distances, ~15 us); for larger ones the
+//                        caller passes h_out = NULL and takes the median of the distance buffer with a
+//                        device-wide sort (500 particles: 124,750 distances, 284 us here against ~100 us).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phk {
+
+constexpr int SV_MAXD = 72;    // P + 3 <= 67
+constexpr int SV_MAXB = 4096;  // particles (the kernel row of one particle lives in LDS)
+constexpr int SV_NT = 256;
+
+struct SVArgs {
+    int64_t B;
+    int D;
+    const double* x;      // [B, D]
+    const double* g;      // [B, D] grad log p
+    double* mu;           // [B, D] in/out
+    double* nu;
+    double* nu_max;
+    const double* h_in;   // device scalar
+    double* x_out;        // [B, D]
+    double den1, den2;    // 1 - b1^count, 1 - b2^count
+    double lr, b1, b2, eps;
+};
+
+__global__ __launch_bounds__(SV_NT) void svgd_update_kernel(SVArgs A) {
+    __shared__ double xj[SV_MAXD];
+    __shared__ double kj[SV_MAXB];  // k(x_i, x_j) for all i
+    __shared__ double red[SV_NT];
+    const int j = blockIdx.x, t = threadIdx.x, D = A.D;
+    const double h = *A.h_in;
+    for (int d = t; d < D; d += SV_NT) xj[d] = A.x[(int64_t)j * D + d];
+    __syncthreads();
+    for (int64_t i = t; i < A.B; i += SV_NT) {
+        const double* xi = A.x + i * D;
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double df = xi[d] - xj[d];
+            d2 = fma(df, df, d2);
+        }
+        kj[i] = exp(-d2 / h);
+    }
+    __syncthreads();
+    // sum over i: the workgroup is cut into PARTS groups of D lanes (lane = coordinate: consecutive lanes read
+    // consecutive addresses of x and g); part p takes i = p, p + PARTS, ...; the parts are then added in part
+    // order by one lane per coordinate, so the result does not depend on timing (bit-reproducible)
+    const int parts = SV_NT / D;
+    const int part = t / D, d = t - part * D;
+    const double two_over_h = 2.0 / h;
+    double s = 0.0;
+    if (part < parts) {
+        for (int64_t i = part; i < A.B; i += parts) s += kj[i] * (two_over_h * (A.x[i * D + d] - xj[d]) - A.g[i * D + d]);
+        red[part * D + d] = s;
+    }
+    __syncthreads();
+    if (t < D) {
+        double tot = 0.0;
+        for (int p = 0; p < parts; ++p) tot += red[p * D + t];
+        const double phi = tot / (double)A.B;
+        const int64_t o = (int64_t)j * D + t;
+        const double mu = A.b1 * A.mu[o] + (1.0 - A.b1) * phi;
+        const double nu = A.b2 * A.nu[o] + (1.0 - A.b2) * phi * phi;
+        const double mu_hat = mu / A.den1, nu_hat = nu / A.den2;
+        const double nm = fmax(A.nu_max[o], nu_hat);
+        A.mu[o] = mu;
+        A.nu[o] = nu;
+        A.nu_max[o] = nm;
+        A.x_out[o] = xj[t] - A.lr * mu_hat / (sqrt(nm) + A.eps);
+    }
+}
+
+// distances of the strict lower triangle, row-major: pair p <-> (i, j), i > j, p = i (i - 1) / 2 + j
+__global__ void pair_dist_kernel(const double* __restrict__ x, int64_t B, int D, double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = B * (B - 1) / 2;
+    if (p >= n) return;
+    int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const int64_t j = p - i * (i - 1) / 2;
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double df = x[i * D + d] - x[j * D + d];
+        d2 = fma(df, df, d2);
+    }
+    out[p] = sqrt(d2);
+}
+
+// k-th smallest (0-based) of n non-negative doubles, one workgroup, exact.  Bucket select: min and max of the
+// candidates; a monotone map of [min, max] onto SEL_BINS buckets (so the buckets partition the candidates in
+// order) and a histogram of it -- pairwise distances spread over the buckets, so the LDS atomics do not pile up
+// on one address the way a radix digit of their nearly identical bit patterns would (a radix select took 380
+// us here, 55 us per pass); the bucket holding the k-th element is gathered into LDS and ranked by counting.
+// A bucket too large to gather (many equal values) becomes the new candidate range.
+constexpr int SEL_BINS = 2048, SEL_CAP = 4096;
+
+struct SelShared {
+    int hist[SEL_BINS];
+    double cand[SEL_CAP];
+    unsigned long long mn, mx;
+    int ncand, bucket;
+    long long k_in, below;
+    double result;
+    int done;
+};
+
+__device__ double select_kth(const double* __restrict__ v, int64_t n, int64_t k, SelShared& S) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    unsigned long long lo_key = 0ull, hi_key = ~0ull;  // candidates: lo_key <= key <= hi_key
+    long long k_rel = k;                               // rank of the wanted element among the candidates
+    for (int round = 0; round < 64; ++round) {
+        // min / max of the candidates
+        if (t == 0) {
+            S.mn = ~0ull;
+            S.mx = 0ull;
+        }
+        __syncthreads();
+        unsigned long long mn = ~0ull, mx = 0ull;
+        for (int64_t e = t; e < n; e += nt) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(v[e]);
+            if (key >= lo_key && key <= hi_key) {
+                mn = key < mn ? key : mn;
+                mx = key > mx ? key : mx;
+            }
+        }
+        atomicMin(&S.mn, mn);
+        atomicMax(&S.mx, mx);
+        __syncthreads();
+        const unsigned long long kmn = S.mn, kmx = S.mx;
+        if (kmn == kmx) return __longlong_as_double((long long)kmn);
+        const double vmn = __longlong_as_double((long long)kmn), vmx = __longlong_as_double((long long)kmx);
+        const double scale = (double)(SEL_BINS - 1) / (vmx - vmn);
+        for (int b = t; b < SEL_BINS; b += nt) S.hist[b] = 0;
+        if (t == 0) S.ncand = 0;
+        __syncthreads();
+        for (int64_t e = t; e < n; e += nt) {
+            const double x = v[e];
+            const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+            if (key >= kmn && key <= kmx) {
+                int b = (int)((x - vmn) * scale);
+                b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+                atomicAdd(&S.hist[b], 1);
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            long long kk = k_rel;
+            int b = 0;
+            for (; b < SEL_BINS - 1; ++b) {
+                if (kk < S.hist[b]) break;
+                kk -= S.hist[b];
+            }
+            S.bucket = b;
+            S.k_in = kk;
+        }
+        __syncthreads();
+        const int bsel = S.bucket;
+        const long long k_in = S.k_in;
+        const int c = S.hist[bsel];
+        if (c <= SEL_CAP) {
+            for (int64_t e = t; e < n; e += nt) {
+                const double x = v[e];
+                const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+                if (key >= kmn && key <= kmx) {
+                    int b = (int)((x - vmn) * scale);
+                    b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+                    if (b == bsel) S.cand[atomicAdd(&S.ncand, 1)] = x;
+                }
+            }
+            __syncthreads();
+            for (int e = t; e < c; e += nt) {
+                const double x = S.cand[e];
+                int rank = 0;
+                for (int f = 0; f < c; ++f) rank += (S.cand[f] < x || (S.cand[f] == x && f < e)) ? 1 : 0;
+                if (rank == (int)k_in) S.result = x;
+            }
+            __syncthreads();
+            return S.result;
+        }
+        // too many candidates in that bucket: narrow the range to it (its own min / max next round)
+        unsigned long long bmn = ~0ull, bmx = 0ull;
+        for (int64_t e = t; e < n; e += nt) {
+            const double x = v[e];
+            const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+            if (key >= kmn && key <= kmx) {
+                int b = (int)((x - vmn) * scale);
+                b = b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+                if (b == bsel) {
+                    bmn = key < bmn ? key : bmn;
+                    bmx = key > bmx ? key : bmx;
+                }
+            }
+        }
+        if (t == 0) {
+            S.mn = ~0ull;
+            S.mx = 0ull;
+        }
+        __syncthreads();
+        atomicMin(&S.mn, bmn);
+        atomicMax(&S.mx, bmx);
+        __syncthreads();
+        lo_key = S.mn;
+        hi_key = S.mx;
+        k_rel = k_in;
+        __syncthreads();
+    }
+    return __longlong_as_double((long long)lo_key);  // (not reached: every round shrinks the range)
+}
+
+__global__ __launch_bounds__(1024) void median_kernel(const double* __restrict__ v, int64_t n, int64_t B, double* h_out) {
+    __shared__ SelShared S;
+    if (n <= 0) {  // a single particle: the length scale stays at its initial value 1
+        if (threadIdx.x == 0) *h_out = 1.0;
+        return;
+    }
+    // torch.quantile(v, 0.5), linear interpolation: position 0.5 (n - 1) between two order statistics
+    const double pos = 0.5 * (double)(n - 1);
+    const int64_t lo = (int64_t)floor(pos), hi = (int64_t)ceil(pos);
+    const double vlo = select_kth(v, n, lo, S);
+    __syncthreads();
+    double vhi = vlo;
+    if (hi != lo) vhi = select_kth(v, n, hi, S);
+    if (threadIdx.x == 0) {
+        const double med = vlo + (vhi - vlo) * (pos - (double)lo);
+        *h_out = med * med / log((double)B);
+    }
+}
+
+hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hipStream_t st) {
+    if (a.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(svgd_update_kernel, dim3((unsigned)a.B), dim3(SV_NT), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t n = a.B * (a.B - 1) / 2;
+    if (n > 0) {
+        hipLaunchKernelGGL(pair_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)a.x_out, a.B, a.D, dist_ws);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (h_out != nullptr) hipLaunchKernelGGL(median_kernel, dim3(1), dim3(1024), 0, st, (const double*)dist_ws, n, a.B, h_out);
+    return hipGetLastError();
+}
+
+}  // namespace phk

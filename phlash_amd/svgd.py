@@ -13,10 +13,15 @@ posteriors instead (tests/test_svgd.py).
   phi(x_j) = mean_i [ -k(x_i, x_j) grad log p(x_i) - grad_{x_i} k(x_i, x_j) ];
 * optax.amsgrad: b1 = 0.9, b2 = 0.999, eps = 1e-8, bias-corrected moments, running max of the
   corrected second moment, update = -lr * m_hat / (sqrt(v_max) + eps).
+
+The functions below are the definition (plain torch, CPU-testable).  On the GPU ``step`` runs the same
+update as three HIP launches (``phk_svgd_step``, csrc/svgd_step.hip) instead of ~70 small torch kernels;
+``tests/test_kernel_api.py::test_svgd_step_kernel_matches_the_torch_definition`` holds the two together.
 """
 
 from __future__ import annotations
 
+import ctypes
 import dataclasses
 import math
 
@@ -53,7 +58,7 @@ def median_heuristic(x: torch.Tensor) -> torch.Tensor:
     n = x.shape[0]
     if n < 2:
         return torch.ones((), dtype=x.dtype, device=x.device)
-    d = torch.cdist(x, x)
+    d = torch.cdist(x, x, compute_mode="donot_use_mm_for_euclid_dist")  # differences, not |x|^2 + |y|^2 - 2xy
     iu = torch.tril_indices(n, n, offset=-1, device=x.device)
     med = torch.quantile(d[iu[0], iu[1]], 0.5)
     return med**2 / math.log(n)
@@ -70,8 +75,47 @@ def amsgrad_update(state: SVGDState, g: torch.Tensor, lr: float, b1=0.9, b2=0.99
     return upd, mu, nu, nu_max, count
 
 
-def step(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:
+def step_torch(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:
+    """One SVGD / AMSGrad update, the definition (any device)."""
     phi = functional_gradient(state.particles, grad_logp, state.length_scale)
     upd, mu, nu, nu_max, count = amsgrad_update(state, phi, lr)
     x = state.particles + upd
     return SVGDState(particles=x, length_scale=median_heuristic(x), mu=mu, nu=nu, nu_max=nu_max, count=count)
+
+
+def step_hip(state: SVGDState, grad_logp: torch.Tensor, lr: float, b1=0.9, b2=0.999, eps=1e-8) -> SVGDState:
+    """The same update on the GPU through the C ABI (three launches, no host synchronisation)."""
+    from . import _lib
+
+    x = state.particles.contiguous()
+    assert x.is_cuda and x.dtype == torch.float64 and x.ndim == 2
+    B, D = x.shape
+    g = grad_logp.to(dtype=torch.float64, device=x.device).contiguous()
+    mu, nu, nu_max = state.mu.clone(), state.nu.clone(), state.nu_max.clone()
+    x_out = torch.empty_like(x)
+    h_in = state.length_scale.to(dtype=torch.float64, device=x.device).reshape(1).contiguous()
+    n_pairs = B * (B - 1) // 2
+    in_kernel = n_pairs <= _MEDIAN_IN_KERNEL  # one workgroup selects the median: small populations only
+    h_out = torch.empty(1, dtype=torch.float64, device=x.device)
+    ws = torch.empty(max(n_pairs, 1), dtype=torch.float64, device=x.device)
+    count = state.count + 1
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.load().phk_svgd_step(
+        x.device.index, B, D, x.data_ptr(), g.data_ptr(), mu.data_ptr(), nu.data_ptr(), nu_max.data_ptr(),
+        h_in.data_ptr(), h_out.data_ptr() if in_kernel else None, x_out.data_ptr(), ws.data_ptr(), count, float(lr),
+        b1, b2, eps, ctypes.c_void_p(stream)))
+    if not in_kernel:  # the kernel left the pairwise distances in ws: median by a device-wide sort
+        h_out = torch.quantile(ws, 0.5) ** 2 / math.log(B)
+    return SVGDState(particles=x_out, length_scale=h_out.reshape(()), mu=mu, nu=nu, nu_max=nu_max, count=count)
+
+
+_MEDIAN_IN_KERNEL = 16384  # pairwise distances (181 particles) up to which the single-workgroup select is used
+
+
+def step(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:
+    """One update: the HIP kernels for particles on the GPU (within their limits: <= 4,096 particles of
+    <= 72 coordinates), the torch definition otherwise."""
+    x = state.particles
+    if x.is_cuda and x.dtype == torch.float64 and x.shape[0] <= 4096 and x.shape[1] <= 72:
+        return step_hip(state, grad_logp, lr)
+    return step_torch(state, grad_logp, lr)

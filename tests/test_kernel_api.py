@@ -258,3 +258,33 @@ def test_fit_with_afs_term_and_test_contig():
     assert len(res) == 12
     c = np.stack([np.asarray(dm.eta.c) for dm in res])
     assert np.isfinite(c).all() and (c > 0).all()
+
+
+@pytest.mark.parametrize("B,D", [(1, 18), (2, 5), (7, 3), (100, 18), (101, 18), (500, 18), (64, 67)])
+def test_svgd_step_kernel_matches_the_torch_definition(B, D):
+    """phk_svgd_step (csrc/svgd_step.hip) against phlash_amd/svgd.py, the torch restatement of what the reference
+    delegates to blackjax.svgd + optax.amsgrad (mcmc.py:178-199, 279): particles, both AMSGrad moments, their
+    running maximum and the median-heuristic length scale over several consecutive steps, odd and even numbers
+    of pairwise distances (the median then interpolates between two order statistics), a single particle."""
+    from phlash_amd import svgd
+
+    gen = torch.Generator().manual_seed(B * 100 + D)
+    x = torch.randn(B, D, generator=gen, dtype=torch.float64).cuda()
+    a, b = svgd.init(x.clone()), svgd.init(x.clone())
+    for it in range(5):
+        g = torch.randn(B, D, generator=gen, dtype=torch.float64).cuda() * (1.0 + it)
+        a = svgd.step_torch(a, g, 0.1)
+        b = svgd.step_hip(b, g, 0.1)
+        assert b.count == a.count == it + 1
+        np.testing.assert_allclose(b.particles.cpu(), a.particles.cpu(), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(b.mu.cpu(), a.mu.cpu(), rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(b.nu.cpu(), a.nu.cpu(), rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(b.nu_max.cpu(), a.nu_max.cpu(), rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(float(b.length_scale), float(a.length_scale), rtol=1e-11)
+    # duplicates among the distances (the radix select must land on the right order statistics)
+    x = torch.zeros(6, 2, dtype=torch.float64)
+    x[3:] = 1.0
+    st = svgd.init(x.cuda())
+    t, h = svgd.step_torch(st, torch.zeros_like(st.particles), 0.1), svgd.step_hip(st, torch.zeros_like(st.particles), 0.1)
+    np.testing.assert_allclose(float(h.length_scale), float(t.length_scale), rtol=1e-13)
+    assert svgd.step(st, torch.zeros_like(st.particles), 0.1).particles.is_cuda
