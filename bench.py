@@ -46,6 +46,8 @@ FP32_PEAK_TFLOPS = 157.3  # vector fp32 peak (same guide)
 
 
 CONFIGS = {
+    "cfg1": dict(K=16, particles=1, chunks=1, chunk_size=100000, overlap=0, scaling="weak",
+                 what="cfg1: one 10 Mb sequence, one particle (the reference's CPU-runnable case: pure latency)"),
     "cfg2": dict(K=16, particles=100, chunks=500, chunk_size=60000, overlap=500, scaling="weak",
                  what="cfg2 per GPU: 1 diploid, 3 Gb"),
     "cfg3": dict(K=16, particles=100, chunks=5000, chunk_size=60000, overlap=500, scaling="strong", afs_n=20,

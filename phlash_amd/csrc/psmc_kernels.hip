@@ -223,7 +223,7 @@ template <bool ON>
 struct DenseOps {};
 template <>
 struct DenseOps<true> {
-    float D2[16], D4[16];  // M_h^2 and M_h^4: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
+    float D2[16], D4[16], D8[16];  // M_h^2, M_h^4, M_h^8: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -483,17 +483,20 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         if constexpr (J == 16) return 0.0;
         else return __builtin_fma(dpp_<0x150 + J>(x), m[J], dot_share<J + 1>(x, m));
     }
-    // D2 = M M, D4 = D2 D2 (both forms: slot j of a product is the dense step applied to slot j of
+    // D2 = M M, D4 = D2 D2, D8 = D4 D4 (both forms: slot j of a product is the dense step applied to slot j of
     // the left factor read as a vector spread over the lanes of the row)
     __device__ __forceinline__ void finish_dense(const double (&M)[16]) {
         if constexpr (has_dense<real, K, R>()) {
-            double P2[16];
+            double P2[16], P4[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) P2[j] = dot_share<0>(M[j], M);
 #pragma unroll
+            for (int j = 0; j < 16; ++j) P4[j] = dot_share<0>(P2[j], P2);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
                 this->D2[j] = (float)P2[j];
-                this->D4[j] = (float)dot_share<0>(P2[j], P2);
+                this->D4[j] = (float)P4[j];
+                this->D8[j] = (float)dot_share<0>(P4[j], P4);
             }
         }
     }
@@ -689,6 +692,9 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 #ifndef PHK_DENSE_WAVES
 #define PHK_DENSE_WAVES 2
 #endif
+#ifndef PHK_DENSE8
+#define PHK_DENSE8 1  // A/B: 0 = no M_h^8 step (groups of four sites only)
+#endif
 template <typename real, int K, int R>
 constexpr int scan_waves_per_simd() { return has_dense<real, K, R>() ? PHK_DENSE_WAVES : 1; }
 
@@ -824,29 +830,42 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             // M_h^4 step; else per pair of sites M_h^2 or two structured steps.
             if constexpr (DENSE) {
 #pragma unroll
-                for (int g = 0; g < T / 4; ++g) {
-                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                    if (__all(c4 == 0u)) {
-                        a[0][0] = dense16(a[0][0], lane.D4);
-                    } else {
+                for (int h8 = 0; h8 < T / 8; ++h8) {
+                    // eight hom sites for all four sequences (61 % of the blocks at 5 % hets + 1 % missing): ONE dense
+                    // M_h^8 step and one rescale.  The block's exponent total goes into eblk as ever; the sweep
+                    // re-runs blocks in its own scaling and corrects beta by 2^(e_run - e_fwd).
+                    if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
+                        a[0][0] = dense16(a[0][0], lane.D8);
+                        const int ex = lane.rescale(a);
+                        E += ex;
+                        ex_min = ex < ex_min ? ex : ex_min;
+                        continue;
+                    }
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                            if (__all(c2 == 0u)) {
-                                a[0][0] = dense16(a[0][0], lane.D2);
-                            } else {
-                                real sc;
-                                V e[NP];
-                                lane.emis(c2 & 3, e);
-                                lane.fwd_site(a, e, sc, false);
-                                lane.emis(c2 >> 2, e);
-                                lane.fwd_site(a, e, sc, false);
+                    for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
+                        const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                        if (__all(c4 == 0u)) {
+                            a[0][0] = dense16(a[0][0], lane.D4);
+                        } else {
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                                if (__all(c2 == 0u)) {
+                                    a[0][0] = dense16(a[0][0], lane.D2);
+                                } else {
+                                    real sc;
+                                    V e[NP];
+                                    lane.emis(c2 & 3, e);
+                                    lane.fwd_site(a, e, sc, false);
+                                    lane.emis(c2 >> 2, e);
+                                    lane.fwd_site(a, e, sc, false);
+                                }
                             }
                         }
+                        const int ex = lane.rescale(a);
+                        E += ex;
+                        ex_min = ex < ex_min ? ex : ex_min;
                     }
-                    const int ex = lane.rescale(a);
-                    E += ex;
-                    ex_min = ex < ex_min ? ex : ex_min;
                 }
             }
         } else if (full) {
@@ -1302,26 +1321,34 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
             // where every sequence of the wave is hom over the group (see fwd_kernel)
             if constexpr (DENSE) {
 #pragma unroll
-                for (int g = 3; g >= 0; --g) {
-                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                    if (__all(c4 == 0u)) {
-                        beta[0][0] = dense16(beta[0][0], lane.D4);
-                    } else {
+                for (int h8 = 1; h8 >= 0; --h8) {
+                    if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {  // see fwd_kernel
+                        beta[0][0] = dense16(beta[0][0], lane.D8);
+                        F += lane.rescale(beta);
+                        continue;
+                    }
 #pragma unroll
-                        for (int hh = 1; hh >= 0; --hh) {
-                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                            if (__all(c2 == 0u)) {
-                                beta[0][0] = dense16(beta[0][0], lane.D2);
-                            } else {
-                                V e[NP];
-                                lane.emis(c2 >> 2, e);
-                                lane.bt_site(beta, e, false);
-                                lane.emis(c2 & 3, e);
-                                lane.bt_site(beta, e, false);
+                    for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
+                        const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                        if (__all(c4 == 0u)) {
+                            beta[0][0] = dense16(beta[0][0], lane.D4);
+                        } else {
+#pragma unroll
+                            for (int hh = 1; hh >= 0; --hh) {
+                                const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                                if (__all(c2 == 0u)) {
+                                    beta[0][0] = dense16(beta[0][0], lane.D2);
+                                } else {
+                                    V e[NP];
+                                    lane.emis(c2 >> 2, e);
+                                    lane.bt_site(beta, e, false);
+                                    lane.emis(c2 & 3, e);
+                                    lane.bt_site(beta, e, false);
+                                }
                             }
                         }
+                        F += lane.rescale(beta);
                     }
-                    F += lane.rescale(beta);
                 }
             }
         } else if (ns == 16) {

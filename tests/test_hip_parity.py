@@ -493,8 +493,8 @@ def _runs_data(rng, n, L, het=0.02, miss_runs=3):
 
 @pytest.mark.parametrize("T", [8, 16])
 def test_dense_hom_run_operators_f32(T, rng):
-    """K = 16, R = 16, float32, rescale interval 4: the forward kernel and the beta scan take M_h^4 /
-    M_h^2 steps wherever all four sequences of a wave are hom over the group.  Mixed waves (one
+    """K = 16, R = 16, float32, rescale interval 4: the forward kernel and the beta scan take M_h^8 / M_h^4 /
+    M_h^2 steps wherever all four sequences of a wave are hom over eight / four / two sites.  Mixed waves (one
     sequence all hom, one with hets, one with missing runs), ragged length, warm-up boundaries inside
     and outside dense groups, against the float64 oracle; and the same rows with per-site
     rescaling (structured steps only) as a second opinion."""
@@ -524,7 +524,12 @@ def test_dense_hom_run_operators_f32(T, rng):
         eng.set_rescale_interval(1)  # NRM = 1 instantiations have no dense path
         eng.set_variant(16, T)
         ll3, g3 = _run(eng, P, inds, W)
-        np.testing.assert_allclose(ll, ll3, rtol=1e-5, atol=1e-5)  # dense vs structured-only arithmetic
+        # dense vs structured-only arithmetic.  On the all-hom row (|ll| = 2.3-2.5 at W = 515) the state sits
+        # at its fixed point and every step repeats the SAME rounding, so float32 errors add up coherently:
+        # per-site rescaling with structured steps ends 2.6-3.8e-5 below the oracle there, the dense M_h^8 /
+        # M_h^4 steps (operators built in float64, rounded once) within 0.9e-5 of it (and inside the bar of
+        # _check above) -- up to 3.9e-5 apart from each other
+        np.testing.assert_allclose(ll, ll3, rtol=2e-5, atol=2e-5)
         eng.set_variant(0, 0)
 
 
