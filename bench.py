@@ -259,7 +259,7 @@ def main():
 
     from phlash_amd import parallel, svgd
     from phlash_amd.kernel import get_kernel
-    from phlash_amd.model import afs_term, log_prior
+    from phlash_amd.model import afs_term, log_prior_population
     from phlash_amd.param_map import particles_to_psmc
     from phlash_amd.params import PSMCParams
     from phlash_amd.synth import particle_population, simulate_chunks
@@ -294,7 +294,7 @@ def main():
         pp = particles_to_psmc(template, xs)  # HIP: particle -> PSMCParams (+ Jacobian), one launch
         l2 = parallel.sharded_loglik_sum(kern, pp, inds)  # HIP kernels + the one all-reduce (flags ride along)
         flags.add_(kern._flags)
-        lp = log_prior(mcp) + c1 * l2
+        lp = log_prior_population(template, xs) + c1 * l2  # HIP: prior + its gradient, one launch
         if afs is not None:
             lp = lp + afs_term(mcp.to_dm(), afs)  # model.py:58-68 (torch float64 on the GPU; tiny next to the kernels)
         (g,) = torch.autograd.grad(lp.sum(), xs)

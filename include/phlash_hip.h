@@ -90,6 +90,14 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
 int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x,
                   int64_t B, double* params, double* jac, void* stream);
 
+/* log_prior of the whole population with its gradient, one launch.  Replaces log_prior
+ * (src/phlash/model.py:11-21) under vmap + jax.grad:
+ *   value[b] = logN(log(rho/theta); 0, 1) - alpha * sum_i (log c_{i+1} - log c_i)^2 - beta * |x_b|^2
+ * with rho/theta = 0.1 + 9.9 sigmoid(x[P+2]) and c = softplus(x[2 .. 2+P)) per epoch (params.py:106-118).
+ *   x      device [B, P+3];  value device [B];  grad device [B, P+3] d value / d x, or NULL */
+int phk_log_prior(int device, int P, double alpha, double beta, const double* x, int64_t B, double* value,
+                  double* grad, void* stream);
+
 /* The SVGD / AMSGrad update of the sampler's inner step for the whole population on the device:
  *   phi_j = (1/B) sum_i [ -k_ij g_i + (2/h)(x_i - x_j) k_ij ],  k_ij = exp(-|x_i - x_j|^2 / h);
  *   AMSGrad (b1, b2, eps, bias correction with `count` = the step number starting at 1, running max of the

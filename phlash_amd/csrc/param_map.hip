@@ -244,6 +244,61 @@ __global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
     }
 }
 
+// log_prior of a whole population with its gradient (model.py:11-21): one thread per particle.
+//   value = logN(log(rho/theta); 0, 1) - alpha sum_i (log c_{i+1} - log c_i)^2 - beta |x|^2,
+//   rho/theta = 0.1 + 9.9 sigmoid(x[P+2]) (params.py:110-112), c = softplus(x[2 .. 2+P)) per epoch.
+__global__ void log_prior_kernel(int P, double alpha, double beta, const double* __restrict__ X, int64_t B,
+                                 double* __restrict__ value, double* __restrict__ grad) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int D = P + 3;
+    const double* x = X + b * D;
+    double* g = grad ? grad + b * D : nullptr;
+    double xx = 0.0;
+    for (int i = 0; i < D; ++i) xx += x[i] * x[i];
+    const double r = x[P + 2];
+    const double sg = 1.0 / (1.0 + exp(-r));
+    const double rot = 0.1 + 9.9 * sg;
+    const double z = log(rot);
+    double ret = -0.5 * z * z - 0.91893853320467274178;  // 0.5 log(2 pi)
+    // softplus as torch evaluates it (threshold 20): y > 20 ? y : log1p(exp(y)), derivative 1 : sigmoid(y)
+    auto lc_of = [&](int i, double& dlc) {
+        const double y = x[2 + i];
+        const double sp = y > 20.0 ? y : log1p(exp(y));
+        const double dsp = y > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-y));
+        dlc = dsp / sp;
+        return log(sp);
+    };
+    double dprev = 0.0, dl_prev = 0.0, lc_prev = 0.0, rough = 0.0;
+    for (int i = 0; i < P; ++i) {
+        double dl;
+        const double lc = lc_of(i, dl);
+        const double dcur = i > 0 ? lc - lc_prev : 0.0;  // lc_i - lc_{i-1}
+        if (i > 0) {
+            rough += dcur * dcur;
+            // d/d lc_{i-1} of -alpha sum diff^2 = -2 alpha (d_{i-1} - d_i)
+            if (g) g[2 + i - 1] = -2.0 * alpha * (dprev - dcur) * dl_prev - 2.0 * beta * x[2 + i - 1];
+        }
+        dprev = dcur;
+        dl_prev = dl;
+        lc_prev = lc;
+    }
+    if (g) {
+        g[2 + P - 1] = -2.0 * alpha * dprev * dl_prev - 2.0 * beta * x[2 + P - 1];
+        g[0] = -2.0 * beta * x[0];
+        g[1] = -2.0 * beta * x[1];
+        g[P + 2] = -z * 9.9 * sg * (1.0 - sg) / rot - 2.0 * beta * r;
+    }
+    value[b] = ret - alpha * rough - beta * xx;
+}
+
+hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
+                            hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(log_prior_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, P, alpha, beta, x, B, value, grad);
+    return hipGetLastError();
+}
+
 hipError_t launch_param_map(const PMArgs& a, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(param_map_kernel, dim3((unsigned)a.B), dim3(a.D <= 64 ? 64 : 128), 0, st, a);

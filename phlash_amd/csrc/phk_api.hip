@@ -40,6 +40,8 @@ struct PMArgs {  // must match param_map.hip
     int64_t B;
 };
 hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
+hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
+                            hipStream_t st);
 
 constexpr int SV_MAXD = 72, SV_MAXB = 4096;
 struct SVArgs {  // must match svgd_step.hip
@@ -911,6 +913,17 @@ int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, doubl
     HIP_TRY(hipSetDevice(device));
     hipError_t e = phk::launch_param_map(a, (hipStream_t)stream);
     if (e != hipSuccess) return fail(PHK_EHIP, "param_map kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+int phk_log_prior(int device, int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
+                  void* stream) {
+    if (P < 1 || P > phk::PM_MAXK) return fail(PHK_EINVAL, "P=%d epochs outside [1, %d]", P, phk::PM_MAXK);
+    if (!x || !value) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0) return fail(PHK_EINVAL, "B must be >= 0");
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_log_prior(P, alpha, beta, x, B, value, grad, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "log_prior kernel launch: %s", hipGetErrorString(e));
     return PHK_OK;
 }
 

@@ -223,7 +223,7 @@ template <bool ON>
 struct DenseOps {};
 template <>
 struct DenseOps<true> {
-    float D2[16], D4[16], D8[16];  // M_h^2, M_h^4, M_h^8: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
+    float D2[16], D4[16], D8[16], D16[16];  // M_h^2, ^4, ^8, ^16: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -483,20 +483,23 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         if constexpr (J == 16) return 0.0;
         else return __builtin_fma(dpp_<0x150 + J>(x), m[J], dot_share<J + 1>(x, m));
     }
-    // D2 = M M, D4 = D2 D2, D8 = D4 D4 (both forms: slot j of a product is the dense step applied to slot j of
+    // D2 = M M, D4 = D2 D2, D8 = D4 D4, D16 = D8 D8 (both forms: slot j of a product is the dense step applied to slot j of
     // the left factor read as a vector spread over the lanes of the row)
     __device__ __forceinline__ void finish_dense(const double (&M)[16]) {
         if constexpr (has_dense<real, K, R>()) {
-            double P2[16], P4[16];
+            double P2[16], P4[16], P8[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) P2[j] = dot_share<0>(M[j], M);
 #pragma unroll
             for (int j = 0; j < 16; ++j) P4[j] = dot_share<0>(P2[j], P2);
 #pragma unroll
+            for (int j = 0; j < 16; ++j) P8[j] = dot_share<0>(P4[j], P4);
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
                 this->D2[j] = (float)P2[j];
                 this->D4[j] = (float)P4[j];
-                this->D8[j] = (float)dot_share<0>(P4[j], P4);
+                this->D8[j] = (float)P8[j];
+                this->D16[j] = (float)dot_share<0>(P8[j], P8);
             }
         }
     }
@@ -695,6 +698,12 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 #ifndef PHK_DENSE8
 #define PHK_DENSE8 1  // A/B: 0 = no M_h^8 step (groups of four sites only)
 #endif
+#ifndef PHK_DENSE16
+#define PHK_DENSE16 1  // A/B: 0 = no M_h^16 step
+#endif
+#ifndef PHK_DENSE_LEAN
+#define PHK_DENSE_LEAN 1  // A/B: 0 = no lean piece loops in the one-state-per-lane kernels
+#endif
 template <typename real, int K, int R>
 constexpr int scan_waves_per_simd() { return has_dense<real, K, R>() ? PHK_DENSE_WAVES : 1; }
 
@@ -782,6 +791,66 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             asm volatile("" ::"v"(nx1.x), "v"(nx1.y), "v"(nx1.z), "v"(nx1.w), "v"(nx2.x), "v"(nx2.y), "v"(nx2.z), "v"(nx2.w),
                          "v"(nx3.x), "v"(nx3.y), "v"(nx3.z), "v"(nx3.w));
     }
+    // One full block of the one-state-per-lane layout (DENSE): sixteen / eight / four / two hom sites for all
+    // four sequences of the wave (wave vote) are ONE dense M_h^n step; one rescale per dense step, or per
+    // group of four sites (the NRM = 4 schedule) where structured steps are needed.  All-hom blocks of 8 sites
+    // are 61 % of the blocks at 5 % hets + 1 % missing, of 16 sites 37 %.  The block's exponent total goes
+    // into eblk as ever; the sweep re-runs blocks in its own scaling and corrects beta by 2^(e_run - e_fwd).
+    auto dense_block = [&](const uint32_t codes) {
+        if constexpr (DENSE) {
+            if (T == 16 && PHK_DENSE16 && __all(codes == 0u)) {
+                a[0][0] = dense16(a[0][0], lane.D16);
+                const int ex = lane.rescale(a);
+                E += ex;
+                ex_min = ex < ex_min ? ex : ex_min;
+                return;
+            }
+#pragma unroll
+            for (int h8 = 0; h8 < T / 8; ++h8) {
+                if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
+                    a[0][0] = dense16(a[0][0], lane.D8);
+                    const int ex = lane.rescale(a);
+                    E += ex;
+                    ex_min = ex < ex_min ? ex : ex_min;
+                    continue;
+                }
+#pragma unroll
+                for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
+                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                    if (__all(c4 == 0u)) {
+                        a[0][0] = dense16(a[0][0], lane.D4);
+                    } else {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                            if (__all(c2 == 0u)) {
+                                a[0][0] = dense16(a[0][0], lane.D2);
+                            } else {
+                                real sc;
+                                V e[NP];
+                                lane.emis(c2 & 3, e);
+                                lane.fwd_site(a, e, sc, false);
+                                lane.emis(c2 >> 2, e);
+                                lane.fwd_site(a, e, sc, false);
+                            }
+                        }
+                    }
+                    const int ex = lane.rescale(a);
+                    E += ex;
+                    ex_min = ex < ex_min ? ex : ex_min;
+                }
+            }
+        }
+    };
+    // Lean piece loop of the DENSE kernels.  A block of this layout is ~500 cycles of arithmetic, and the
+    // general block loop below spent as many again on its per-block tests (full block? warm-up boundary?
+    // segment start? which word of the piece?), on 64-bit per-lane store addresses and on exec-mask branches
+    // around the stores (timing-only builds at 500 x 5 x 100,000: 1.31 of 2.64 ms).  A piece of 64 sites that
+    // holds only full blocks and no warm-up boundary takes this path instead: tests once per piece, the
+    // piece's words rotated through one register, wave-uniform store bases with 32-bit lane offsets, and
+    // stores by every lane (lanes past the last sequence repeat its work bit for bit: same value, same address).
+    const bool lean_ok = PHK_DENSE_LEAN && DENSE && (A.seg_blocks % BPC) == 0 && nseq * K < (int64_t(1) << 31);
+    const unsigned ck_off = (unsigned)(seq * K + rank * SPL), sq_off = (unsigned)seq;
     int blk = 0;
     for (int pc = 0; blk < nblk; pc += PPB) {
      const uint4 c0 = pnext, c1 = nx1, c2 = nx2, c3 = nx3;
@@ -799,6 +868,50 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
      for (int q = 0; q < PPB && blk < nblk; ++q) {
       const uint4 pcur = PPB == 1 ? c0 : (q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)));
       const int bend = blk + BPC < nblk ? blk + BPC : nblk;
+      if constexpr (DENSE) {
+          if (lean_ok && blk + BPC <= nfull && (blkW < blk || blkW >= blk + BPC)) {
+              if constexpr (CKPT) {
+                  if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
+                      if (seg_left == 0) {
+                          if (active && rank == 0) *esp = E;
+                          esp += nseq;
+                          seg_left = A.seg_blocks;
+                      }
+                      seg_left -= BPC;
+                  }
+              }
+              real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
+              int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
+              uint32_t w0 = pcur.x, w1 = pcur.y, w2 = pcur.z, w3 = pcur.w;
+#pragma nounroll
+              for (int bi = 0; bi < BPC; ++bi) {
+                  if constexpr (CKPT) {
+                      ck_u[ck_off] = a[0][0];
+                      ck_u += ck_step;
+                  }
+                  const int E0 = E;
+                  dense_block(w0);
+                  if constexpr (CKPT) {
+                      eb_u[sq_off] = (int16_t)(E - E0);
+                      eb_u += nseq;
+                  }
+                  if constexpr (T == 16) {
+                      w0 = w1; w1 = w2; w2 = w3;
+                  } else {
+                      w0 = __builtin_amdgcn_alignbit(w1, w0, 2 * T);
+                      w1 = __builtin_amdgcn_alignbit(w2, w1, 2 * T);
+                      w2 = __builtin_amdgcn_alignbit(w3, w2, 2 * T);
+                      w3 >>= 2 * T;
+                  }
+              }
+              blk += BPC;
+              if constexpr (CKPT) {
+                  ckp += (int64_t)BPC * ck_step;
+                  ebp += (int64_t)BPC * nseq;
+              }
+              continue;
+          }
+      }
       for (int bi = 0; blk < bend; ++blk, ++bi) {
         const int tw = (bi * T) & 15;  // first site of the block inside its word
         const int wsel = (bi * T) >> 4;
@@ -825,49 +938,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         const bool full = blk < nfull && blk != blkW;  // T sites, no warm-up boundary inside
         const int ns = blk < nfull ? T : tail;
         if (DENSE && full) {
-            // full block in the latency-bound layout: groups of 4 sites, one rescale per group (the
-            // NRM = 4 schedule).  All four sequences of the wave hom over the group: one dense
-            // M_h^4 step; else per pair of sites M_h^2 or two structured steps.
-            if constexpr (DENSE) {
-#pragma unroll
-                for (int h8 = 0; h8 < T / 8; ++h8) {
-                    // eight hom sites for all four sequences (61 % of the blocks at 5 % hets + 1 % missing): ONE dense
-                    // M_h^8 step and one rescale.  The block's exponent total goes into eblk as ever; the sweep
-                    // re-runs blocks in its own scaling and corrects beta by 2^(e_run - e_fwd).
-                    if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
-                        a[0][0] = dense16(a[0][0], lane.D8);
-                        const int ex = lane.rescale(a);
-                        E += ex;
-                        ex_min = ex < ex_min ? ex : ex_min;
-                        continue;
-                    }
-#pragma unroll
-                    for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
-                        const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                        if (__all(c4 == 0u)) {
-                            a[0][0] = dense16(a[0][0], lane.D4);
-                        } else {
-#pragma unroll
-                            for (int hh = 0; hh < 2; ++hh) {
-                                const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                                if (__all(c2 == 0u)) {
-                                    a[0][0] = dense16(a[0][0], lane.D2);
-                                } else {
-                                    real sc;
-                                    V e[NP];
-                                    lane.emis(c2 & 3, e);
-                                    lane.fwd_site(a, e, sc, false);
-                                    lane.emis(c2 >> 2, e);
-                                    lane.fwd_site(a, e, sc, false);
-                                }
-                            }
-                        }
-                        const int ex = lane.rescale(a);
-                        E += ex;
-                        ex_min = ex < ex_min ? ex : ex_min;
-                    }
-                }
-            }
+            dense_block(codes);
         } else if (full) {
             // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
             // the scheduler can lift every emission ds_read to the top and overlap sites
@@ -1299,9 +1370,70 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     int pc = w >> 2;
     uint4 pnext = pieces[pc > 0 ? pc : 0];
     if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
+    // one whole word (16 sites, right to left) of the one-state-per-lane layout: dense M_h^16 / M_h^8 / M_h^4 /
+    // M_h^2 steps where every sequence of the wave is hom over the sites they cover (see fwd_kernel)
+    auto dense_word = [&](const uint32_t codes) {
+        if constexpr (DENSE) {
+            if (PHK_DENSE16 && __all(codes == 0u)) {
+                beta[0][0] = dense16(beta[0][0], lane.D16);
+                F += lane.rescale(beta);
+                return;
+            }
+#pragma unroll
+            for (int h8 = 1; h8 >= 0; --h8) {
+                if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
+                    beta[0][0] = dense16(beta[0][0], lane.D8);
+                    F += lane.rescale(beta);
+                    continue;
+                }
+#pragma unroll
+                for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
+                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
+                    if (__all(c4 == 0u)) {
+                        beta[0][0] = dense16(beta[0][0], lane.D4);
+                    } else {
+#pragma unroll
+                        for (int hh = 1; hh >= 0; --hh) {
+                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
+                            if (__all(c2 == 0u)) {
+                                beta[0][0] = dense16(beta[0][0], lane.D2);
+                            } else {
+                                V e[NP];
+                                lane.emis(c2 >> 2, e);
+                                lane.bt_site(beta, e, false);
+                                lane.emis(c2 & 3, e);
+                                lane.bt_site(beta, e, false);
+                            }
+                        }
+                    }
+                    F += lane.rescale(beta);
+                }
+            }
+        }
+    };
     for (; w >= 0; --pc) {
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];
+      if constexpr (DENSE) {
+          // lean path (see fwd_kernel): a piece of four whole words, none of them the row's last (partial)
+          // word: the words rotate through one register, the segment-start test is the only one left
+          if (PHK_DENSE_LEAN && w == pc * 4 + 3 && w < nw - 1) {
+              uint32_t w3 = pcur.w, w2 = pcur.z, w1 = pcur.y, w0 = pcur.x;
+#pragma nounroll
+              for (int k = 0; k < 4; ++k, --w) {
+                  if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
+                      real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
+                      dst[0] = beta[0][0];
+                      fseg_out[(int64_t)sb * nseq + seq] = F;
+                      --sb;
+                      w_store -= seg_words;
+                  }
+                  dense_word(w3);
+                  w3 = w2; w2 = w1; w1 = w0;
+              }
+              continue;
+          }
+      }
       for (const int wlo = pc * 4; w >= wlo; --w) {
         const int wsel = w & 3;
         const uint32_t codes = wsel == 0 ? pcur.x : (wsel == 1 ? pcur.y : (wsel == 2 ? pcur.z : pcur.w));
@@ -1317,40 +1449,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         }
         const int ns = w == nw - 1 ? tail : 16;
         if (DENSE && ns == 16) {
-            // groups of 4 sites, right to left, one rescale per group; dense M_h^4 / M_h^2 steps
-            // where every sequence of the wave is hom over the group (see fwd_kernel)
-            if constexpr (DENSE) {
-#pragma unroll
-                for (int h8 = 1; h8 >= 0; --h8) {
-                    if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {  // see fwd_kernel
-                        beta[0][0] = dense16(beta[0][0], lane.D8);
-                        F += lane.rescale(beta);
-                        continue;
-                    }
-#pragma unroll
-                    for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
-                        const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                        if (__all(c4 == 0u)) {
-                            beta[0][0] = dense16(beta[0][0], lane.D4);
-                        } else {
-#pragma unroll
-                            for (int hh = 1; hh >= 0; --hh) {
-                                const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                                if (__all(c2 == 0u)) {
-                                    beta[0][0] = dense16(beta[0][0], lane.D2);
-                                } else {
-                                    V e[NP];
-                                    lane.emis(c2 >> 2, e);
-                                    lane.bt_site(beta, e, false);
-                                    lane.emis(c2 & 3, e);
-                                    lane.bt_site(beta, e, false);
-                                }
-                            }
-                        }
-                        F += lane.rescale(beta);
-                    }
-                }
-            }
+            dense_word(codes);
         } else if (ns == 16) {
             V ec[NP];
             lane.emis(codes >> 30, ec);

@@ -31,7 +31,7 @@ from . import parallel, svgd
 from .afs import bws_transform, fold_transform
 from .data import init_mcmc_data
 from .kernel import get_kernel
-from .model import afs_term, log_prior
+from .model import afs_term, log_prior_population
 from .param_map import particles_to_psmc
 from .params import MCMCParams
 from .size_history import DemographicModel, SizeHistory
@@ -45,7 +45,7 @@ def _log_density_population(x, template: MCMCParams, c, kern, local_inds, afs, a
     term is summed over every rank's share of the minibatch)."""
     mcp = template.from_flat(x)
     pp = particles_to_psmc(template, x)  # HIP: to_dm + from_dm for the whole population, one launch
-    l1 = log_prior(mcp)
+    l1 = log_prior_population(template, x)
     l2 = parallel.sharded_loglik_sum(kern, pp, local_inds, reduce=reduce).to(x.device)
     l3 = afs_term(mcp.to_dm(), afs, afs_transform) if afs is not None and len(afs) > 1 else torch.zeros_like(l1)
     ret = c[0] * l1 + c[1] * l2 + c[2] * l3

@@ -33,6 +33,40 @@ def log_prior(mcp: MCMCParams) -> torch.Tensor:
     return ret
 
 
+class _LogPriorHip(torch.autograd.Function):
+    """``log_prior`` of a population on the GPU: one launch for the values and d/dx (phk_log_prior),
+    instead of ~20 small launches forward and ~30 backward by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, P, alpha, beta):
+        import ctypes
+
+        from . import _lib
+
+        x = x.contiguous()
+        B = x.shape[0]
+        val = torch.empty(B, dtype=F64, device=x.device)
+        grad = torch.empty_like(x) if x.requires_grad else None
+        _lib.check(_lib.load().phk_log_prior(x.device.index, int(P), float(alpha), float(beta), x.data_ptr(), B,
+                                             val.data_ptr(), grad.data_ptr() if grad is not None else None,
+                                             ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g[:, None] * grad, None, None, None
+
+
+def log_prior_population(template: MCMCParams, x: torch.Tensor) -> torch.Tensor:
+    """``log_prior(template.from_flat(x))`` for particles x [B, P+3]; on the GPU through the fused kernel."""
+    if x.is_cuda and x.dtype == F64 and x.ndim == 2:
+        return _LogPriorHip.apply(x, x.shape[1] - 3, float(template.alpha), float(template.beta))
+    return log_prior(template.from_flat(x))
+
+
 def afs_term(dm, afs, afs_transform=None) -> torch.Tensor:
     """sum xlogy(T afs, T esfs), esfs = etbl / sum(etbl)  (model.py:58-68).  [...]"""
     afs = torch.as_tensor(np.asarray(afs, dtype=np.float64), dtype=F64, device=dm.eta.t.device)

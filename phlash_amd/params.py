@@ -46,7 +46,13 @@ class PSMCParams(NamedTuple):
         return M
 
     def stack(self) -> torch.Tensor:
-        """[..., 7, K] in the kernel's row order (gpu.py:189: np.stack(pp, -2))."""
+        """[..., 7, K] in the kernel's row order (gpu.py:189: np.stack(pp, -2)).  Fields that are still the
+        seven rows of one [..., 7, K] tensor (``unstack`` of the parameter-map kernel's output) give that
+        tensor back: no copy, and autograd reaches it directly instead of through seven slice-backward
+        kernels each followed by an accumulation."""
+        whole = _rows_of_one_tensor(self)
+        if whole is not None:
+            return whole
         return torch.stack([torch.as_tensor(a) for a in self], -2)
 
     @classmethod
@@ -79,6 +85,24 @@ class PSMCParams(NamedTuple):
         u = torch.cat([sup / v1, zero], -1)  # params.py:46, 50
         v = torch.cat([zero, v1], -1)
         return cls(b=b, d=d, u=u, v=v, emis0=emis0, emis1=emis1, pi=pi)
+
+
+def _rows_of_one_tensor(pp: "PSMCParams"):
+    first = pp[0]
+    if not isinstance(first, torch.Tensor) or first._base is None:
+        return None
+    whole = first._base
+    if whole.ndim != first.ndim + 1 or tuple(whole.shape) != (*first.shape[:-1], 7, first.shape[-1]):
+        return None
+    for i, a in enumerate(pp):
+        if not isinstance(a, torch.Tensor) or a._base is None:
+            return None
+        row = whole[..., i, :]
+        if (a._base.data_ptr() != whole.data_ptr() or a._base.shape != whole.shape or a._base.stride() != whole.stride()
+                or a.storage_offset() != row.storage_offset() or a.shape != row.shape or a.stride() != row.stride()
+                or a.dtype != whole.dtype or a.requires_grad != whole.requires_grad):
+            return None
+    return whole
 
 
 @dataclasses.dataclass

@@ -104,8 +104,12 @@ def step_hip(state: SVGDState, grad_logp: torch.Tensor, lr: float, b1=0.9, b2=0.
         x.device.index, B, D, x.data_ptr(), g.data_ptr(), mu.data_ptr(), nu.data_ptr(), nu_max.data_ptr(),
         h_in.data_ptr(), h_out.data_ptr() if in_kernel else None, x_out.data_ptr(), ws.data_ptr(), count, float(lr),
         b1, b2, eps, ctypes.c_void_p(stream)))
-    if not in_kernel:  # the kernel left the pairwise distances in ws: median by a device-wide sort
-        h_out = torch.quantile(ws, 0.5) ** 2 / math.log(B)
+    if not in_kernel:
+        # the kernel left the pairwise distances in ws: median by a device-wide sort (torch.quantile sorts too,
+        # but also checks its input for NaN on the host -- a synchronisation in the middle of the step)
+        srt = torch.sort(ws).values
+        med = 0.5 * (srt[(n_pairs - 1) // 2] + srt[n_pairs // 2])
+        h_out = med * med / math.log(B)
     return SVGDState(particles=x_out, length_scale=h_out.reshape(()), mu=mu, nu=nu, nu_max=nu_max, count=count)
 
 

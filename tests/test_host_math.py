@@ -212,3 +212,27 @@ def test_afs_transforms_match_reference_captured_vectors():
         np.testing.assert_allclose(got, G[k], rtol=1e-10, atol=1e-14, err_msg=k)
         n_checked += 1
     assert n_checked >= 50
+
+
+def test_stack_of_unstacked_rows_is_the_same_tensor():
+    """PSMCParams.unstack(x).stack() hands x back (no copy; autograd reaches x directly), and anything else
+    -- a replaced field, fields that were never rows of one tensor, rows of a larger tensor -- is stacked."""
+    import torch
+
+    from phlash_amd.params import PSMCParams
+
+    x = torch.randn(5, 7, 4, dtype=torch.float64, requires_grad=True)
+    y = x * 2
+    pp = PSMCParams.unstack(y)
+    s = pp.stack()
+    assert s.data_ptr() == y.data_ptr() and s.shape == y.shape
+    (s * torch.arange(4.0)).sum().backward()
+    assert torch.equal(x.grad, (2 * torch.arange(4.0, dtype=torch.float64)).expand(5, 7, 4))
+    changed = pp._replace(emis0=pp.emis0 + 1.0)
+    s2 = changed.stack()
+    assert s2.data_ptr() != y.data_ptr() and torch.equal(s2[:, 4], y[:, 4] + 1.0) and torch.equal(s2[:, 5], y[:, 5])
+    z = torch.randn(3, 2, 7, 4, dtype=torch.float64)
+    assert torch.equal(PSMCParams.unstack(z[:, 1]).stack(), z[:, 1])
+    assert PSMCParams(*[torch.ones(3) for _ in range(7)]).stack().shape == (7, 3)
+    swapped = pp._replace(b=pp.d, d=pp.b)  # rows of the same tensor in another order
+    assert torch.equal(swapped.stack()[:, 0], y[:, 1])

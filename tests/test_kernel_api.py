@@ -288,3 +288,34 @@ def test_svgd_step_kernel_matches_the_torch_definition(B, D):
     t, h = svgd.step_torch(st, torch.zeros_like(st.particles), 0.1), svgd.step_hip(st, torch.zeros_like(st.particles), 0.1)
     np.testing.assert_allclose(float(h.length_scale), float(t.length_scale), rtol=1e-13)
     assert svgd.step(st, torch.zeros_like(st.particles), 0.1).particles.is_cuda
+
+
+@pytest.mark.parametrize("P,alpha,beta", [(15, 0.0, 0.0), (15, 1e-2, 1e-4), (1, 0.3, 0.1), (31, 2.0, 0.5)])
+def test_log_prior_kernel_matches_the_torch_definition(P, alpha, beta):
+    """phk_log_prior (one launch: values and d/dx of a population) against ``model.log_prior`` differentiated by
+    autograd (model.py:11-21 of the reference), including particles with c_tr beyond torch's softplus
+    threshold of 20 and far in the tails of the rho/theta sigmoid."""
+    from phlash_amd.model import log_prior, log_prior_population
+    from phlash_amd.params import MCMCParams
+
+    pattern = f"{P}*1" if P > 1 else "3*1"
+    P = 3 if P == 1 else P
+    template = MCMCParams.from_linear(pattern, 1e-4, 15.0, np.ones(P), 1e-2, 1e-2, alpha=alpha, beta=beta)
+    rng = np.random.default_rng(P)
+    x = torch.tensor(template.flat.numpy() + rng.normal(size=(257, P + 3)) * 2.0)
+    x[0, 2:2 + P] = 25.0  # softplus(y) = y
+    x[1, 2] = 20.0
+    x[2, 2] = 20.000001
+    x[3, -1] = 30.0
+    x[4, -1] = -30.0
+    xr = x.clone().requires_grad_(True)
+    ref = log_prior(template.from_flat(xr))
+    (gref,) = torch.autograd.grad(ref.sum(), xr)
+    xd = x.cuda().requires_grad_(True)
+    val = log_prior_population(template, xd)
+    w = torch.linspace(0.5, 1.5, x.shape[0], dtype=torch.float64)
+    (g,) = torch.autograd.grad((val * w.cuda()).sum(), xd)
+    np.testing.assert_allclose(val.detach().cpu(), ref.detach(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g.cpu(), gref * w[:, None], rtol=1e-10, atol=1e-12)
+    with torch.no_grad():
+        np.testing.assert_allclose(log_prior_population(template, x.cuda()).cpu(), ref.detach(), rtol=1e-12, atol=1e-12)
