@@ -76,8 +76,8 @@ def test_two_ranks_reproduce_one(tmp_path, shard, scenario):
 
 def test_bench_two_ranks_gloo(tmp_path):
     """bench.py's own step (param map -> kernels -> all-reduce -> chain rule -> SVGD) with two ranks on
-    the real kernels, tiny shapes; bench.py asserts that the replicated particles are identical on all
-    ranks after the timed loop."""
+    the real kernels, tiny shapes; bench.py reports whether the replicated particles are identical on all
+    ranks after the timed loop, and they must be."""
     port = str(_free_port())
     procs = []
     for r in range(2):
@@ -98,4 +98,5 @@ def test_bench_two_ranks_gloo(tmp_path):
         assert p.returncode == 0, outs[r][1][-3000:]
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["ranks_identical_after_timed_loop"] is True
     assert not any(ln.startswith("{") for ln in outs[1][0].splitlines())  # only rank 0 prints the JSON line
