@@ -491,6 +491,77 @@ def _runs_data(rng, n, L, het=0.02, miss_runs=3):
     return data
 
 
+def _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, dbl):
+    """the gradient metric of test_random_shapes_against_the_oracle (see there): worst error / bound"""
+    g, g_ref = g.copy(), g_ref.copy()
+    g[..., 6, :] *= P[..., 6, :]
+    g_ref[..., 6, :] *= P[..., 6, :]
+    own = np.abs(g_ref).max(axis=-1, keepdims=True)
+    own[..., 6, :] = np.maximum(own[..., 6, :], 1.0)
+    full = np.zeros_like(own)
+    if W > 0:
+        _, g_full = cport.batch(Pin, data, inds, 0)
+        g_full[..., 6, :] *= P[..., 6, :]
+        full = np.abs(g_full).max(axis=-1, keepdims=True)
+    err_row = np.abs(g - g_ref).max(axis=-1, keepdims=True)
+    a, c = (F64_GRAD_OWN, F64_GRAD_FULL) if dbl else (F32_GRAD_OWN, F32_GRAD_FULL)
+    return float((err_row / (a * own + c * full + 1e-300)).max())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PHK_DENSE_FUZZ_SEEDS", "48"))))
+def test_dense_kernels_random_shapes(seed):
+    """The one-state-per-lane kernels (K = 16, float32, rescale interval 4: dense M_h^16 ... M_h^2 steps, lean
+    piece loops for whole 64-site pieces, general loop at the row ends and around the warm-up boundary) on
+    seeded random draws of everything their control flow depends on: row length 1 ... 3,000 (no whole
+    piece, exactly whole pieces, ragged), warm-up boundary anywhere, het rate 0 ... 5 %, runs of missing
+    sites, a batch that leaves lane groups of the last wave without a sequence, checkpoint interval 8 / 16,
+    and the launch form (serial sweep behind the dense forward kernel; segmented: dense forward kernel
+    beside the dense beta scan; hybrid with a random split) -- against the float64 oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 127, 128, 512, 513, 1024, int(rng.integers(1, 3001)), int(rng.integers(1, 3001))]))
+    W = int(rng.choice([0, 0, int(rng.integers(0, L + 1)), L, max(L - 1, 0), min(64, L), min(63, L), min(65, L)]))
+    B, S = int(rng.integers(1, 8)), int(rng.integers(1, 6))
+    N = S + int(rng.integers(0, 3))
+    het = float(rng.choice([0.0, 0.005, 0.02, 0.05]))
+    data = (rng.uniform(size=(N, L)) < het).astype(np.int8)
+    for r in range(N):
+        for _ in range(int(rng.integers(0, 3))):
+            s0 = int(rng.integers(0, L))
+            data[r, s0:s0 + int(rng.integers(1, 50))] = -1
+    data[(data == -1).all(axis=1), 0] = 0
+    inds = rng.integers(0, N, size=S)
+    P = _params(16, B, 1, seed=seed)
+    Pin = P.astype(np.float32).astype(np.float64)
+    T = int(rng.choice([8, 16]))
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    eng.set_rescale_interval(4)
+    form = int(rng.integers(3))
+    hybrid = None
+    if form == 0:
+        eng.set_variant(16, T)
+    elif form == 1:
+        eng.set_plan(1, R=4, T=T, R_forward=16, R_scan=16)
+    elif B * S >= 2:
+        hybrid = f"{int(rng.choice([2, 4, 16]))}:16:{int(rng.integers(1, B * S))}:4:16"
+    else:
+        eng.set_plan(1, R=2, T=8, R_forward=16, R_scan=16)
+    if hybrid:
+        os.environ["PHK_HYBRID"] = hybrid
+    try:
+        ll, g = _run(eng, P, inds, W)
+        ll0 = _run(eng, P, inds, W, grad=False)
+    finally:
+        os.environ.pop("PHK_HYBRID", None)
+    ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=1e-5)
+    worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
+    print(f"dense fuzz seed={seed} B={B} S={S} L={L} W={W} het={het} T={T} form={form} hybrid={hybrid}: err/bound {worst:.2f}")
+    assert worst < 1.0
+    assert not eng.underflow_risk()
+
+
 @pytest.mark.parametrize("T", [8, 16])
 def test_dense_hom_run_operators_f32(T, rng):
     """K = 16, R = 16, float32, rescale interval 4: the forward kernel and the beta scan take M_h^8 / M_h^4 /
