@@ -701,6 +701,9 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 #ifndef PHK_DENSE16
 #define PHK_DENSE16 1  // A/B: 0 = no M_h^16 step
 #endif
+#ifndef PHK_FWD_LEAN
+#define PHK_FWD_LEAN 1  // A/B: 0 = lean piece loops in the one-state-per-lane kernels only (1: in every forward kernel and beta scan)
+#endif
 #ifndef PHK_DENSE_LEAN
 #define PHK_DENSE_LEAN 1  // A/B: 0 = no lean piece loops in the one-state-per-lane kernels
 #endif
@@ -842,6 +845,28 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             }
         }
     };
+    // one full block of the other layouts: a straight-line basic block of T sites (no per-site branches), the
+    // emission row of the next site in flight while the current one computes
+    auto straight_block = [&](const uint32_t codes) {
+        V ec[NP];
+        lane.emis(codes & 3, ec);
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            V en[NP];
+            if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
+            real sc;
+            const int ex = lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
+            E += ex;
+            if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
+            if (i + 1 < T) {
+#pragma unroll
+                for (int h = 0; h < NP; ++h) ec[h] = en[h];
+            }
+#if PHK_FWD_SITE_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
     // Lean piece loop of the DENSE kernels.  A block of this layout is ~500 cycles of arithmetic, and the
     // general block loop below spent as many again on its per-block tests (full block? warm-up boundary?
     // segment start? which word of the piece?), on 64-bit per-lane store addresses and on exec-mask branches
@@ -849,7 +874,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // holds only full blocks and no warm-up boundary takes this path instead: tests once per piece, the
     // piece's words rotated through one register, wave-uniform store bases with 32-bit lane offsets, and
     // stores by every lane (lanes past the last sequence repeat its work bit for bit: same value, same address).
-    const bool lean_ok = PHK_DENSE_LEAN && DENSE && (A.seg_blocks % BPC) == 0 && nseq * K < (int64_t(1) << 31);
+    constexpr bool LEAN = PPB == 1 && (DENSE ? PHK_DENSE_LEAN != 0 : (PHK_FWD_LEAN != 0 && PHK_EMIS_AHEAD < 2));
+    const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K < (int64_t(1) << 31);
     const unsigned ck_off = (unsigned)(seq * K + rank * SPL), sq_off = (unsigned)seq;
     int blk = 0;
     for (int pc = 0; blk < nblk; pc += PPB) {
@@ -868,7 +894,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
      for (int q = 0; q < PPB && blk < nblk; ++q) {
       const uint4 pcur = PPB == 1 ? c0 : (q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)));
       const int bend = blk + BPC < nblk ? blk + BPC : nblk;
-      if constexpr (DENSE) {
+      if constexpr (LEAN) {
           if (lean_ok && blk + BPC <= nfull && (blkW < blk || blkW >= blk + BPC)) {
               if constexpr (CKPT) {
                   if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
@@ -886,11 +912,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 #pragma nounroll
               for (int bi = 0; bi < BPC; ++bi) {
                   if constexpr (CKPT) {
-                      ck_u[ck_off] = a[0][0];
+#pragma unroll
+                      for (int i = 0; i < SPL; ++i) ck_u[ck_off + i] = L::get(a, i);
                       ck_u += ck_step;
                   }
                   const int E0 = E;
-                  dense_block(w0);
+                  if constexpr (DENSE) dense_block(w0);
+                  else straight_block(w0);
                   if constexpr (CKPT) {
                       eb_u[sq_off] = (int16_t)(E - E0);
                       eb_u += nseq;
@@ -959,24 +987,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 __builtin_amdgcn_sched_barrier(0);
             }
 #else
-            V ec[NP];
-            lane.emis(codes & 3, ec);
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                V en[NP];  // next site's emission row is in flight while this site computes
-                if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
-                real sc;
-                const int ex = lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
-                E += ex;
-                if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
-                if (i + 1 < T) {
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
-                }
-#if PHK_FWD_SITE_BARRIER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-            }
+            straight_block(codes);
 #endif
         } else {
 #pragma unroll
@@ -1370,6 +1381,22 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     int pc = w >> 2;
     uint4 pnext = pieces[pc > 0 ? pc : 0];
     if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
+    // one whole word (16 sites, right to left) of the other layouts: straight-line, next emission row in flight
+    auto straight_word = [&](const uint32_t codes) {
+        V ec[NP];
+        lane.emis(codes >> 30, ec);
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            V en[NP];
+            if (j > 0) lane.emis((codes >> (2 * (j - 1))) & 3, en);
+            F += lane.bt_site(beta, ec, rescale_after<NRM>(j));
+            if (j > 0) {
+#pragma unroll
+                for (int h = 0; h < NP; ++h) ec[h] = en[h];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // one whole word (16 sites, right to left) of the one-state-per-lane layout: dense M_h^16 / M_h^8 / M_h^4 /
     // M_h^2 steps where every sequence of the wave is hom over the sites they cover (see fwd_kernel)
     auto dense_word = [&](const uint32_t codes) {
@@ -1414,21 +1441,23 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     for (; w >= 0; --pc) {
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];
-      if constexpr (DENSE) {
+      if constexpr (DENSE ? PHK_DENSE_LEAN != 0 : PHK_FWD_LEAN != 0) {
           // lean path (see fwd_kernel): a piece of four whole words, none of them the row's last (partial)
           // word: the words rotate through one register, the segment-start test is the only one left
-          if (PHK_DENSE_LEAN && w == pc * 4 + 3 && w < nw - 1) {
+          if (w == pc * 4 + 3 && w < nw - 1) {
               uint32_t w3 = pcur.w, w2 = pcur.z, w1 = pcur.y, w0 = pcur.x;
 #pragma nounroll
               for (int k = 0; k < 4; ++k, --w) {
                   if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
                       real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
-                      dst[0] = beta[0][0];
+#pragma unroll
+                      for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
                       fseg_out[(int64_t)sb * nseq + seq] = F;
                       --sb;
                       w_store -= seg_words;
                   }
-                  dense_word(w3);
+                  if constexpr (DENSE) dense_word(w3);
+                  else straight_word(w3);
                   w3 = w2; w2 = w1; w1 = w0;
               }
               continue;
@@ -1451,19 +1480,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         if (DENSE && ns == 16) {
             dense_word(codes);
         } else if (ns == 16) {
-            V ec[NP];
-            lane.emis(codes >> 30, ec);
-#pragma unroll
-            for (int j = 15; j >= 0; --j) {
-                V en[NP];
-                if (j > 0) lane.emis((codes >> (2 * (j - 1))) & 3, en);
-                F += lane.bt_site(beta, ec, rescale_after<NRM>(j));
-                if (j > 0) {
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            straight_word(codes);
         } else {
 #pragma unroll
             for (int j = 15; j >= 0; --j) {
