@@ -245,20 +245,29 @@ class PSMCKernel:
         self._eng.take_flags_async(dst)
         self._flags = dst
 
-    def check_rescaling(self, collective: bool = False) -> bool:
+    def check_rescaling(self, collective: bool = False, also: torch.Tensor | None = None) -> bool:
         """True (after switching to per-site rescaling) if an evaluation since the last check hit
         parameters too extreme for the current rescale interval; the caller should redo that step.
         ``collective``: decide from the flags that travelled in the last all-reduce
         (``take_flags_into``), which are the same on every rank, so that all ranks take the same
         branch -- a rank-local decision followed by a redo that contains a collective would desynchronise
-        the ranks.  Raises AssertionError if a chunk index was out of range (gpu.py:197-199)."""
+        the ranks.  ``also``: a one-element device tensor the caller wants on the host as well; it travels
+        in the same device-to-host copy (one synchronisation instead of two) and is left in
+        ``self.also_value`` (float).  Raises AssertionError if a chunk index was out of range (gpu.py:197-199)."""
+        self.also_value = None
         if collective and self._flags is not None:
-            under, bad = (float(v) for v in self._flags.cpu())  # synchronises
+            if also is not None:
+                both = torch.cat([self._flags.reshape(2), also.reshape(1).to(self._flags.dtype)]).cpu()  # synchronises
+                under, bad, self.also_value = (float(v) for v in both)
+            else:
+                under, bad = (float(v) for v in self._flags.cpu())  # synchronises
             self._flags = None
             assert bad == 0, f"a chunk index was outside [0, N={self.N})"
             risk = under > 0
         else:
             risk = self._eng.underflow_risk()
+            if also is not None:
+                self.also_value = float(also)
         if risk:
             warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
             self._eng.set_rescale_interval(1)

@@ -67,10 +67,16 @@ class _NoRows:
     def take_flags_into(self, dst):
         self._flags = dst  # nothing of its own to hand over: dst stays zero on this rank
 
-    def check_rescaling(self, collective: bool = False) -> bool:
+    def check_rescaling(self, collective: bool = False, also=None) -> bool:
+        self.also_value = None
         if self._flags is None:
+            if also is not None:
+                self.also_value = float(also)
             return False
-        under, bad = (float(v) for v in self._flags.cpu())
+        if also is not None:
+            under, bad, self.also_value = (float(v) for v in torch.cat([self._flags.reshape(2), also.reshape(1).to(F64)]).cpu())
+        else:
+            under, bad = (float(v) for v in self._flags.cpu())
         self._flags = None
         assert bad == 0, "a chunk index was out of range on another rank"
         return under > 0
@@ -233,14 +239,15 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
 
         def elpd(xs):
             val, k_ = elpd_once(xs)
-            if k_.check_rescaling(collective=True):  # same decision on every rank (flags were all-reduced)
+            # same decision on every rank (flags were all-reduced); the value comes back in the same copy
+            if k_.check_rescaling(collective=True, also=val):
                 val, k_ = elpd_once(xs)
-                k_.check_rescaling(collective=True)
-            return float(val)
+                k_.check_rescaling(collective=True, also=val)
+            return k_.also_value
 
     c_train = torch.tensor([1.0, N / S, 1.0], dtype=F64, device=dev)  # mcmc.py:240-247
 
-    cb = options.get("callback") or (lambda *a, **k: None)
+    cb = options.get("callback")  # (the models are only assembled for a callback that wants them)
 
     def dms(xs) -> DemographicModel:
         dm = template.from_flat(xs.detach()).to_dm()
@@ -278,14 +285,19 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     for i in it:
         inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
         g = grad_logp(inds)
+        # The update is launched before the host looks at anything (it does not modify `state`), and the
+        # kernel flags and the finiteness of the new particles then come back in ONE device-to-host copy.
         # An extreme particle may need per-site rescaling (the kernel raises a device flag).  The flag
         # travelled in the step's all-reduce, so every rank reads the same value here and all of them
         # redo the step (which contains another all-reduce) or none does.
-        if train_kern.check_rescaling(collective=True):
+        new_state = svgd.step(state, g, lr)
+        finite = torch.isfinite(new_state.particles).all()
+        if train_kern.check_rescaling(collective=True, also=finite):
             g = grad_logp(inds)
-            train_kern.check_rescaling(collective=True)
-        state = svgd.step(state, g, lr)
-        assert bool(torch.isfinite(state.particles).all())  # mcmc.py:281-285
+            new_state = svgd.step(state, g, lr)
+            train_kern.check_rescaling(collective=True, also=torch.isfinite(new_state.particles).all())
+        assert train_kern.also_value == 1.0, "particles went non-finite"  # mcmc.py:281-285
+        state = new_state
         if elpd is not None and i % 10 == 0:
             e = elpd(state.particles)
             ema = e if ema is None else 0.9 * ema + 0.1 * e
@@ -293,7 +305,8 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                 best_elpd = (i, ema)
             if i - best_elpd[0] > elpd_cutoff:
                 break
-        cb(dms(state.particles))
+        if cb is not None:
+            cb(dms(state.particles))
 
     out = dms(state.particles)
     t, c = out.eta.t.cpu(), out.eta.c.cpu()
