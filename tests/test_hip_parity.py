@@ -536,6 +536,10 @@ def test_dense_kernels_random_shapes(seed):
     eng = _engine(16, data, False)
     eng.set_autotune(False)
     eng.set_rescale_interval(4)
+    slabbed = bool(rng.integers(4) == 0)
+    if slabbed:  # a checkpoint store too small for the batch: the call is cut into particle or chunk slabs
+        per_seq = ((L + 7) // 8) * 16 * 4
+        eng.set_workspace_limit(int(per_seq * rng.integers(1, max(2, (B * S) // 2 + 1))))  # at most half the batch per launch
     form = int(rng.integers(3))
     hybrid = None
     if form == 0:
@@ -550,14 +554,18 @@ def test_dense_kernels_random_shapes(seed):
         os.environ["PHK_HYBRID"] = hybrid
     try:
         ll, g = _run(eng, P, inds, W)
+        slab = eng.get_slab() if slabbed else None
         ll0 = _run(eng, P, inds, W, grad=False)
     finally:
         os.environ.pop("PHK_HYBRID", None)
+    if slabbed and B * S > 1:
+        assert slab[0] * slab[1] < B * S, slab
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=1e-5)
     worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
-    print(f"dense fuzz seed={seed} B={B} S={S} L={L} W={W} het={het} T={T} form={form} hybrid={hybrid}: err/bound {worst:.2f}")
+    print(f"dense fuzz seed={seed} B={B} S={S} L={L} W={W} het={het} T={T} form={form} hybrid={hybrid} slab={slab}: "
+          f"err/bound {worst:.2f}")
     assert worst < 1.0
     assert not eng.underflow_risk()
 
