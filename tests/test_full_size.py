@@ -229,6 +229,15 @@ def test_cfg5_full_size():
     _full_size_case(32, 500, 500, 60_000, 500, expect_slabs=True)
 
 
+def test_production_shape_full_size():
+    """The reference's production shape (mcmc.py:119-121: 500 particles x a minibatch of 5 chunks; 100,000 scored
+    windows + 500 warm-up per chunk): 2,500 sequences, the segmented plan with the one-state-per-lane forward
+    kernel and beta scan (dense M_h^16 ... M_h^2 steps, lean piece loops) at full row length."""
+    eng = _full_size_case(16, 500, 5, 100_000, 500)
+    plan = eng.get_plan()
+    assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
+
+
 def test_cfg3_one_rank_share_through_log_density():
     """cfg3: 10 diploids x 3 Gb = 5,000 chunks, K = 16, 100 particles, sharded over 8 GPUs by chunk
     rows: one rank's share is 625 rows.  The whole objective (prior + HMM term + AFS term for n = 20
