@@ -119,37 +119,16 @@ struct PMArgs {
     int64_t B;
 };
 
+// One pass over the hidden states with O(1) state per thread: round 1's version kept t, c, ect, the transition
+// factors and the survival differences in per-thread arrays of dual numbers indexed by a run-time k (9 KB of
+// scratch per thread), and spent most of its 130 us per launch on scratch traffic.  Same operations in the
+// same order, so the same bits.
 __global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
     const int K = A.K, D = A.D;
     const int64_t bidx = blockIdx.x;
     const int j = threadIdx.x;  // tangent carried by this thread (threads >= D carry a zero tangent)
     const double* x = A.x + bidx * D;
     auto X = [&](int i) { return mk(x[i], i == j ? 1.0 : 0.0); };
-
-    // ---- MCMCParams.to_dm (params.py:94-127) -------------------------------------------------
-    const Dual t1 = dexp(X(0));
-    const Dual tM = t1 + dexp(X(1));
-    const Dual lt1 = dlog(t1), ltM = dlog(tM);
-    Dual t[PM_MAXK], c[PM_MAXK];
-    t[0] = mk(0.0);
-    for (int k = 0; k < K - 1; ++k) t[k + 1] = dexp(lt1 + (ltM - lt1) * ((double)k / (double)(K - 2)));
-    for (int k = 0; k < K; ++k) c[k] = dsoftplus(X(2 + A.epoch[k]));
-    const Dual rho = (0.1 + 9.9 * dsigmoid(X(2 + A.P))) * A.theta;
-
-    // ---- SizeHistory.ect (size_history.py:170-193) -------------------------------------------
-    Dual ect[PM_MAXK];
-    for (int k = 0; k < K - 1; ++k) {
-        const Dual dt = t[k + 1] - t[k];
-        Dual e;
-        if (is_close0(c[k].v)) e = (t[k] + t[k + 1]) / 2.0;
-        else if (isinf(c[k].v) || c[k].v > 100.0) e = t[k];
-        else e = 1.0 / c[k] + t[k] - dt * dexpm1inv(c[k] * dt);
-        ect[k] = e;
-    }
-    ect[K - 1] = t[K - 1] + 1.0 / c[K - 1];
-    for (int k = 0; k < K; ++k)
-        if (ect[k].v < 1e-20) ect[k] = mk(1e-20);
-
     const double lo = 1e-20, hi = 1.0 - 1e-20;
     double* out = A.params + bidx * 7 * K;
     double* jac = A.jac ? A.jac + bidx * 7 * K * D : nullptr;
@@ -158,90 +137,105 @@ __global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
         if (jac && j < D) jac[(size_t)(row * K + k) * D + j] = val.d;
     };
 
-    // ---- emissions and pi (params.py:36-43, size_history.py:123-138) --------------------------
+    // ---- MCMCParams.to_dm (params.py:94-127): t = [0, geomspace(t1, tM, K-1)], c by epoch, rho -------------
+    const Dual t1 = dexp(X(0));
+    const Dual tM = t1 + dexp(X(1));
+    const Dual lt1 = dlog(t1), ltM = dlog(tM);
+    auto t_of = [&](int k) { return k == 0 ? mk(0.0) : dexp(lt1 + (ltM - lt1) * ((double)(k - 1) / (double)(K - 2))); };
+    const Dual rho = (0.1 + 9.9 * dsigmoid(X(2 + A.P))) * A.theta;
+
+    Dual tk = mk(0.0);                                  // t[k]
+    Dual H = mk(0.0), Sprev = mk(1.0), csum = mk(0.0);  // survival (size_history.py:123-138)
+    Row3 row{mk(1.0), mk(0.0), mk(0.0)};                // row 0 of the running 3x3 products (transition.py:52)
+    Dual Rt2_prev = mk(0.0);                            // ... its last entry at t[k]
+    Dual p1_first = mk(0.0), p1_prev = mk(0.0);         // p1[0], p1[k-1]
+    Dual cum = mk(1.0), A01 = mk(1.0);                  // prod_{0<l<k} p2[l], A[0][1]
+    put(3, 0, mk(0.0));
     for (int k = 0; k < K; ++k) {
-        const Dual uu = ect[k] * A.theta;
-        put(4, k, dclamp(dexp(-uu), lo, hi));
-        put(5, k, dclamp(-dexpm1(-uu), lo, hi));
-    }
-    {
-        Dual H = mk(0.0), Sprev = mk(1.0), csum = mk(0.0);
-        Dual Ci[PM_MAXK];
-        for (int k = 0; k < K - 1; ++k) {
-            H = H + c[k] * (t[k + 1] - t[k]);
+        const bool last = k == K - 1;
+        const Dual tk1 = last ? tk : t_of(k + 1);  // t[k+1]
+        const Dual ck = dsoftplus(X(2 + A.epoch[k]));
+        // ---- SizeHistory.ect (size_history.py:170-193) --------------------------------------
+        Dual e;
+        if (!last) {
+            const Dual dt = tk1 - tk;
+            if (is_close0(ck.v)) e = (tk + tk1) / 2.0;
+            else if (isinf(ck.v) || ck.v > 100.0) e = tk;
+            else e = 1.0 / ck + tk - dt * dexpm1inv(ck * dt);
+        } else {
+            e = tk + 1.0 / ck;
+        }
+        if (e.v < 1e-20) e = mk(1e-20);
+        // ---- emissions (params.py:36-43) ------------------------------------------------------
+        {
+            const Dual uu = e * A.theta;
+            put(4, k, dclamp(dexp(-uu), lo, hi));
+            put(5, k, dclamp(-dexpm1(-uu), lo, hi));
+        }
+        // ---- pi (size_history.py:123-138): pi[k] = surv[k-1] - surv[k] for k >= 1 ----------------
+        if (!last) {
+            H = H + ck * (tk1 - tk);
             const Dual S = dexp(-H);
             if (k > 0) {
-                Ci[k - 1] = Sprev - S;
-                csum = csum + Ci[k - 1];
+                const Dual Ci = Sprev - S;
+                csum = csum + Ci;
+                put(6, k, dclamp(Ci, lo, hi));
             }
             Sprev = S;
+        } else {
+            csum = csum + Sprev;  // surv[K-2] - 0
+            put(6, k, dclamp(Sprev, lo, hi));
         }
-        Ci[K - 2] = Sprev;  // surv[K-2] - 0
-        csum = csum + Ci[K - 2];
-        put(6, 0, dclamp(1.0 - csum, lo, hi));
-        for (int k = 1; k < K; ++k) put(6, k, dclamp(Ci[k - 1], lo, hi));
-    }
-
-    // ---- transition factors (transition.py:37-83), row 0 of the running products --------------
-    // augmented grid [t0, e0, t1, e1, ...]; state at t_k is Rt[k], at ect_k is Re[k]
-    Row3 row{mk(1.0), mk(0.0), mk(0.0)};
-    Dual Rt2_prev = mk(0.0);  // Rt[k][2]
-    Dual lower[PM_MAXK], diag[PM_MAXK], p1[PM_MAXK], p2[PM_MAXK], p3[PM_MAXK];
-    for (int k = 0; k < K; ++k) {
-        // t_k -> ect_k with rate c_k
+        // ---- transition factors (transition.py:37-83) -----------------------------------------
+        // augmented grid [t0, e0, t1, e1, ...]: t_k -> ect_k with rate c_k
         {
-            const Dual dt = ect[k] - t[k];
-            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * c[k]);
+            const Dual dt = e - tk;
+            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * ck);
         }
         const Row3 Re = row;
-        const Dual c_adj = c[k];  // c * (n - 1), n = 2
-        Dual q, keep;
-        if (k < K - 1) {
-            const Dual gap = (t[k + 1] - ect[k]) * c_adj;
+        const Dual c_adj = ck;  // c * (n - 1), n = 2
+        Dual q, keep, p2k, p3k;
+        if (!last) {
+            const Dual gap = (tk1 - e) * c_adj;
             q = -dexpm1(-gap);
             keep = dexp(-gap);
-            const Dual dtk = t[k + 1] - t[k];
-            p2[k] = dclamp(dexp(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
-            p3[k] = dclamp(-dexpm1(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
+            const Dual dtk = tk1 - tk;
+            p2k = dclamp(dexp(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
+            p3k = dclamp(-dexpm1(-dtk * c_adj), 1e-8, 1.0 - 1e-8);
         } else {
             q = mk(1.0);
             keep = mk(0.0);
-            p2[k] = mk(1e-8);
-            p3[k] = mk(1.0 - 1e-8);
+            p2k = mk(1e-8);
+            p3k = mk(1.0 - 1e-8);
         }
-        diag[k] = Re.r0 + Re.r1 * q + Re.r2 - Rt2_prev;  // transition.py:60-67
-        p1[k] = dclamp(Re.r1 * keep, 1e-8, 1.0 - 1e-8);
+        put(1, k, dclamp(Re.r0 + Re.r1 * q + Re.r2 - Rt2_prev, lo, hi));  // diagonal, transition.py:60-67
+        const Dual p1k = dclamp(Re.r1 * keep, 1e-8, 1.0 - 1e-8);
         // ect_k -> t_{k+1} with rate c_k (the last interval ends in the absorbing Pinf)
-        if (k < K - 1) {
-            const Dual dt = t[k + 1] - ect[k];
-            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * c[k]);
-            lower[k] = row.r2 - Rt2_prev;  // transition.py:58
+        if (!last) {
+            const Dual dt = tk1 - e;
+            if (!is_close0(dt.v)) row = step_expQ(row, 2.0 * dt * rho, dt * ck);
+            put(0, k, dclamp(row.r2 - Rt2_prev, lo, hi));  // sub-diagonal, transition.py:58
             Rt2_prev = row.r2;
+        } else {
+            put(0, k, mk(0.0));
         }
-    }
-
-    // ---- (b, d, u, v) of params.py:44-55 --------------------------------------------------------
-    for (int k = 0; k < K; ++k) {
-        put(0, k, k < K - 1 ? dclamp(lower[k], lo, hi) : mk(0.0));
-        put(1, k, dclamp(diag[k], lo, hi));
-    }
-    {
-        // first row above the diagonal A[0][jj] = p1[0] * prod_{0<l<jj} p2[l] * p3[jj]
-        Dual cum = mk(1.0), A01 = mk(1.0), vprev = mk(0.0);
-        put(3, 0, mk(0.0));
-        for (int jj = 1; jj < K; ++jj) {
-            const Dual A0j = dclamp(p1[0] * cum * p3[jj], lo, hi);
-            if (jj == 1) A01 = A0j;
-            const Dual vj = A0j / A01;
-            put(3, jj, vj);
-            // u[jj-1] = A[jj-1][jj] / v[jj],  A[i][i+1] = p1[i] * p3[i+1]
-            put(2, jj - 1, dclamp(p1[jj - 1] * p3[jj], lo, hi) / vj);
-            cum = cum * p2[jj];
-            vprev = vj;
+        // ---- (u, v) of params.py:44-55: first row above the diagonal A[0][k] = p1[0] prod_{0<l<k} p2[l] p3[k]
+        if (k == 0) {
+            p1_first = p1k;
+        } else {
+            const Dual A0k = dclamp(p1_first * cum * p3k, lo, hi);
+            if (k == 1) A01 = A0k;
+            const Dual vk = A0k / A01;
+            put(3, k, vk);
+            // u[k-1] = A[k-1][k] / v[k],  A[i][i+1] = p1[i] * p3[i+1]
+            put(2, k - 1, dclamp(p1_prev * p3k, lo, hi) / vk);
+            cum = cum * p2k;
         }
-        (void)vprev;
-        put(2, K - 1, mk(0.0));
+        p1_prev = p1k;
+        tk = tk1;
     }
+    put(2, K - 1, mk(0.0));
+    put(6, 0, dclamp(1.0 - csum, lo, hi));
 }
 
 // log_prior of a whole population with its gradient (model.py:11-21): one thread per particle.
