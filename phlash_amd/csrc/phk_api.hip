@@ -240,6 +240,21 @@ int64_t n_units(const phk_handle* h, int T, int64_t W) {
     return nseg - segW;
 }
 
+// The one-state-per-lane beta scan with its dense hom-run steps (K = 16, float32, rescale interval 4) pays inside the
+// hybrid plan only if the four sequences of a wave read the SAME chunk (the wave vote for a dense step then succeeds
+// as often as one sequence alone would), i.e. if the segment-swept range is a range of whole particles:
+// psmc_kernels.hip maps such a range chunk-major.  So a hybrid plan that asks for R2 = 16 gets its split rounded down
+// to a multiple of S -- unless that takes more than 2 % of the serial sweep's sequences away (then R2 = 2, the
+// structured scan, with the split as it was).  Measured at cfg2: beta scan 14.0 -> 12.2 ms, step -1.1 ms.
+bool dense_scan_ok(const phk_handle* h) { return h->K == 16 && !h->dbl && h->nrm == 4 && valid_Rf(h, 16); }
+Plan adjust_hybrid(const phk_handle* h, Plan p, int64_t S) {
+    if (p.segmented || p.hybrid_first <= 0 || p.R2 != 16) return p;
+    const int64_t rect = S > 0 ? (p.hybrid_first / S) * S : 0;
+    if (dense_scan_ok(h) && rect > 0 && (p.hybrid_first - rect) * 50 <= p.hybrid_first) p.hybrid_first = rect;
+    else p.R2 = valid_Rf(h, 2) ? 2 : p.R2;
+    return p;
+}
+
 // the plan when nothing was forced or tuned
 Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
     Plan p;
@@ -279,7 +294,7 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
             valid_T(h->K, 4, 8) && valid_Rf(h, 2)) {
             p.hybrid_first = first;
             p.R3 = 4;
-            p.R2 = 2;
+            p.R2 = dense_scan_ok(h) ? 16 : 2;  // (16: see adjust_hybrid, applied once the launch shape is known)
         }
     }
     return p;
@@ -500,13 +515,16 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         if (first > 0 && nseq - first > per_round / 20) {
             Plan hbest_plan;
             float hbest = 0.f;
-            const int cand[3][2] = {{4, 2}, {2, 2}, {4, 4}};  // (segment sweep, beta scan) lanes per sequence
+            const int cand[5][2] = {{4, 2}, {2, 2}, {4, 4}, {4, 16}, {2, 16}};  // (segment sweep, beta scan) lanes per sequence
             for (const auto& c : cand) {
                 if (!valid_Rs(h, c[0]) || !valid_T(K, c[0], 8) || !valid_Rf(h, c[1])) continue;
+                if (c[1] == 16 && !dense_scan_ok(h)) continue;
                 Plan hyb = best;
                 hyb.hybrid_first = first;
                 hyb.R3 = c[0];
                 hyb.R2 = c[1];
+                hyb = adjust_hybrid(h, hyb, a.S);
+                if (c[1] == 16 && hyb.R2 != 16) continue;  // (the split cannot be a range of whole particles here)
                 float ms = 0.f;
                 if ((rc = timed(a, hyb, true, &ms)) != PHK_OK) return rc;
                 if (hbest == 0.f || ms < hbest) { hbest = ms; hbest_plan = hyb; }
@@ -1032,7 +1050,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         int rc = autotune(h, l, make_args(0, std::min(Bs, B), 0, std::min(Ss, S)), want_grad, st);
         if (rc != PHK_OK) return rc;
     }
-    const Plan plan = choose_plan(h, nseq_launch, W, want_grad ? 1 : 0);
+    const Plan plan = adjust_hybrid(h, choose_plan(h, nseq_launch, W, want_grad ? 1 : 0), std::min(Ss, S));
     if (!(want_grad ? (plan.segmented ? valid_Rs(h, plan.R) : valid_Rb(h, plan.R)) : valid_Rf(h, plan.R)) || !valid_T(K, plan.R, plan.T))
         return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
     if (want_grad && !plan.segmented && plan.hybrid_first > 0 && !valid_Rs(h, plan.R3)) return fail(PHK_EINVAL, "segment sweep R=%d not available for K=%d", plan.R3, K);

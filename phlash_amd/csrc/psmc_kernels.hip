@@ -730,9 +730,10 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // alone would (hom^4 per group instead of hom^16).
     const int64_t lin = active ? gid : seq_hi - 1;
     int64_t bb, ss;
-    if (has_dense<real, K, R>() && A.seq_begin == 0 && seq_hi == nseq) {
-        ss = lin / A.B;
-        bb = lin - ss * A.B;
+    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
+        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, l = lin - A.seq_begin;
+        ss = l / nb;
+        bb = b0 + (l - ss * nb);
     } else {
         bb = lin / A.S;
         ss = lin - bb * A.S;
@@ -1347,9 +1348,10 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     // alone would (hom^4 per group instead of hom^16).
     const int64_t lin = active ? gid : seq_hi - 1;
     int64_t bb, ss;
-    if (has_dense<real, K, R>() && A.seq_begin == 0 && seq_hi == nseq) {
-        ss = lin / A.B;
-        bb = lin - ss * A.B;
+    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
+        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, l = lin - A.seq_begin;
+        ss = l / nb;
+        bb = b0 + (l - ss * nb);
     } else {
         bb = lin / A.S;
         ss = lin - bb * A.S;

@@ -295,7 +295,21 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     ll, g = eng.run(P, inds, W, grad=True)
     plan = eng.get_plan()
     assert plan.get("hybrid_first") == 32768 and plan["R_segment_sweep"] == 4
+    # ... and with the one-state-per-lane (dense hom-run) beta scan, for which the library rounds the split down
+    # to whole particles (65 x 500) so that the four sequences of a scan wave share their chunk
+    monkeypatch.setenv("PHK_HYBRID", "2:1:32768:4:16")
+    ll_d, g_d = eng.run(P, inds, W, grad=True)
+    plan = eng.get_plan()
+    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16, plan
     monkeypatch.delenv("PHK_HYBRID")
+    eng.set_autotune(True)
+    eng.set_deterministic(True)  # the static rule picks exactly that plan for this shape
+    ll_r, g_r = eng.run(P, inds, W, grad=True)
+    plan = eng.get_plan()
+    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 4, plan
+    assert torch.equal(ll_r, ll_d) and torch.equal(g_r, g_d)
+    eng.set_deterministic(False)
+    eng.set_autotune(False)
     eng.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
     ll_s, g_s = eng.run(P, inds, W, grad=True)
     assert torch.isfinite(g).all()
@@ -304,6 +318,7 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     ll_ref, g_ref = cport.batch(P[sub].float().double().cpu().numpy(), data, chunks, W)
     np.testing.assert_allclose(ll[sub][:, chunks].cpu().numpy(), ll_ref, rtol=1e-5)
     scale = np.maximum(np.abs(g_ref).max(-1, keepdims=True), 1.0)
-    for name, gg in (("hybrid", g), ("serial", g_s)):
+    np.testing.assert_allclose(ll_d.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
+    for name, gg in (("hybrid", g), ("hybrid, dense scan", g_d), ("serial", g_s)):
         err = (np.abs(gg[sub][:, chunks].double().cpu().numpy() - g_ref) / scale).max()
         assert err < 2e-3, (name, err)

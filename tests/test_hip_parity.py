@@ -547,7 +547,10 @@ def test_dense_kernels_random_shapes(seed):
     elif form == 1:
         eng.set_plan(1, R=4, T=T, R_forward=16, R_scan=16)
     elif B * S >= 2:
-        hybrid = f"{int(rng.choice([2, 4, 16]))}:16:{int(rng.integers(1, B * S))}:4:16"
+        first = int(rng.integers(1, B * S))
+        if B >= 2 and rng.integers(2):  # a split between whole particles: the dense beta scan is kept (else: R = 2)
+            first = S * int(rng.integers(1, B))
+        hybrid = f"{int(rng.choice([2, 4, 16]))}:16:{first}:4:16"
     else:
         eng.set_plan(1, R=2, T=8, R_forward=16, R_scan=16)
     if hybrid:
