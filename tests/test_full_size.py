@@ -105,7 +105,7 @@ def test_cfg2_f32_gradient_in_particle_space():
     kernels, per particle |g32 - g64| / |g64|.  Bar: <= 1e-3 for every particle, and -- on a bounded
     sample both can run (all particles x 8 chunks, no warm-up) -- no worse than the reference's OWN float32
     kernel is against its float64 kernel on identical inputs (oracle/_ref, gpu.py:575-692 compiled
-    unmodified).  Measured (profiles/r02c_bench_cfg2.json): ours 2.3e-4 max / 3.4e-5 median on the full
+    unmodified).  Measured (profiles/r02d_bench_cfg2.json): ours 2.3e-4 max / 3.4e-5 median on the full
     batch; on the sample ours 1.8e-4 / 2.7e-5, the reference's float32 kernel 5.2e-4 / 5.7e-5."""
     import bench
     from phlash_amd.kernel import get_kernel
