@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no torchrun environment (RANK / WORLD_SIZE unset) this process touches no GPU: it starts N fresh
+rank processes of itself (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT set), relays rank 0's
+single JSON line and exits with the worst child status.  ``python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`` works as before (the ranks find their environment and run directly).
+
 One *step* = one pass of the hot path over one batch: B particles (unconstrained vectors on the
 GPU) -> PSMCParams for every particle (HIP kernel, float64, with Jacobian) -> HIP forward + checkpointed
 backward kernels over all B x S (particle, chunk) sequences -> sum over chunks -> ONE all-reduce of
@@ -74,6 +79,10 @@ def parse():
     ap.add_argument("--overlap", type=int, default=None)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for tests that "
                     "put two ranks on one GPU)")
+    ap.add_argument("--het-rate", type=float, default=None, help="i.i.d. rows with this het rate (+1 %% missing) "
+                    "instead of rows simulated from the HMM at theta = 1e-2 (which have ~1 %% hets)")
+    ap.add_argument("--theta", type=float, default=1e-2, help="theta = rho per window of the simulated rows")
+    ap.add_argument("--same-plan", type=int, default=1, help="N > 1: install rank 0's tuned plan on every rank (default 1)")
     ap.add_argument("--double", action="store_true", help="float64 kernels (default float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
@@ -223,14 +232,79 @@ def gradient_parity_leg(template, x0, data, W, dev, kern32, max_ref_chunks=8, ma
     return out
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` typed plainly: start N fresh rank processes of this script, one per GPU, relay
+    rank 0's JSON line to stdout, return the worst exit status.  This process never initialises the GPU (no
+    torch.cuda call precedes this), and nothing is re-executed: the ranks are children."""
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PHK_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=True))
+    import threading
+
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    first_fail = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_fail is None:
+            first_fail = time.monotonic()
+        # a rank that died leaves its peers waiting in a collective: give them a minute, then end exactly
+        # the processes started above
+        if first_fail is not None and time.monotonic() - first_fail > 60:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    reader.join(timeout=10)
+    rcs = [p.returncode for p in procs]
+    out = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if not ln.lstrip().startswith("{"):
+            sys.stderr.write(ln)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr, flush=True)
+    if out:
+        sys.stdout.write(out[-1] if out[-1].endswith("\n") else out[-1] + "\n")
+        sys.stdout.flush()
+    elif not worst:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        worst = 1
+    return min(worst, 255)
+
+
 def main():
     a = parse()
+    if "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running with {world} rank(s)", file=sys.stderr, flush=True)
+    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible (there is no CPU path to benchmark)")
+    if local_rank >= ndev:
+        if a.backend == "nccl":
+            sys.exit(f"bench.py: LOCAL_RANK={local_rank} but only {ndev} HIP device(s) visible; RCCL needs one GPU per rank "
+                     f"(--backend gloo lets several ranks share a GPU, for tests)")
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun: init even at world size 1
@@ -271,7 +345,22 @@ def main():
     else:  # every rank owns its own S chunks of a (world x S)-chunk genome set
         S_total = world * S
     # (rows are i.i.d. draws from the model, so "rank r's rows" is a seed; particles are shared)
-    data = simulate_chunks(K, S, W + L, seed=1000 + rank)
+    if a.het_rate is not None:  # i.i.d. rows (the reference's conftest generator, tests/conftest.py:19-21) + 1 % missing
+        g = np.random.default_rng(1000 + rank)
+        data = (g.random((S, W + L), dtype=np.float32) < a.het_rate).astype(np.int8)
+        data.flat[g.integers(0, data.size, size=int(0.01 * data.size))] = -1
+        data[:, 0] = np.maximum(data[:, 0], 0)
+        data_note = f"i.i.d. Bernoulli({a.het_rate:g}) hets + 1 % missing"
+    else:
+        data = simulate_chunks(K, S, W + L, seed=1000 + rank, theta=a.theta, rho=a.theta)
+        data_note = f"rows simulated from the default {K}-state HMM at theta = rho = {a.theta:g} per window + 1 % missing"
+    n16 = (data.shape[1] // 16) * 16
+    data_stats = {
+        "generator": data_note,
+        "het_rate": float((data == 1).mean()),
+        "missing_rate": float((data == -1).mean()),
+        "all_hom_word16_frac": float((data[:, :n16].reshape(data.shape[0], -1, 16) == 0).all(-1).mean()),
+    }
     afs = None
     if a.afs_n:  # cfg3: 10 diploids -> n = 20 haploids, a smooth synthetic spectrum
         afs = 1e5 / np.arange(1, a.afs_n, dtype=np.float64)
@@ -305,8 +394,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         state = one_step(state)
+        if i == 0 and use_dist and world > 1 and a.same_plan and not a.variant:
+            # the first step tuned a plan on every rank by timing; all ranks run the same shapes, so install
+            # rank 0's choice everywhere (otherwise the step time is the max over N independently chosen plans)
+            mine = kern._eng.get_plan()
+            keys = ("segmented", "R", "T", "R_forward", "R_scan", "hybrid_first", "R_segment_sweep")
+            pt = torch.tensor([int(mine.get(k, 0)) if rank == 0 else 0 for k in keys], dtype=torch.int64, device=dev)
+            dist.all_reduce(pt)  # = broadcast from rank 0
+            kern._eng.install_plan(dict(zip(keys, (int(v) for v in pt.cpu()))))
     barrier()
     kern._eng.timing_totals()  # drop the warm-up steps' events
     t0 = time.perf_counter()
@@ -316,10 +413,25 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP events recorded around the kernels on their launch stream, resolved once, after the loop
     fwd_ms, bwd_ms, _n = kern._eng.timing_totals()
+    plan = kern._eng.get_plan()
+    per_rank = None
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+        # one gather of [elapsed, fwd ms, bwd ms, plan...] per rank; the step time is the MAX over ranks
+        pkeys = ("segmented", "R", "T", "R_forward", "R_scan", "hybrid_first", "R_segment_sweep")
+        mine = torch.tensor([elapsed, fwd_ms, bwd_ms] + [float(plan.get(k, 0)) for k in pkeys], dtype=torch.float64, device=dev)
+        allr = torch.zeros((world, mine.numel()), dtype=torch.float64, device=dev)
+        allr[rank] = mine  # (an all-reduce of one-hot rows: the one collective both RCCL and gloo offer for GPU tensors)
+        dist.all_reduce(allr)
+        allr = allr.cpu().numpy()
+        elapsed = float(allr[:, 0].max())
+        per_rank = {
+            "ms_per_step": {"min": float(allr[:, 0].min()) / a.steps * 1e3, "max": elapsed / a.steps * 1e3,
+                            "all": [round(float(v) / a.steps * 1e3, 3) for v in allr[:, 0]]},
+            "forward_ms": [round(float(v) / a.steps, 3) for v in allr[:, 1]],
+            "backward_ms": [round(float(v) / a.steps, 3) for v in allr[:, 2]],
+            "plan": [":".join(str(int(v)) for v in row[3:]) for row in allr],
+            "plan_fields": ":".join(pkeys),
+        }
     assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
     assert float(flags[1]) == 0, "a chunk index was out of range"
     assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
@@ -355,7 +467,6 @@ def main():
             except Exception:
                 traffic = None
         flops = 48.0 * K * B * S * L  # fwd 12K + re-run 12K + backward 24K per site.particle
-        plan = kern._eng.get_plan()
         R, T = plan["R"], plan["T"]
         out = {
             "metric": "site·particle forward+grad evals/sec at K=16; log-lik rel-err vs JAX ref",
@@ -370,11 +481,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if a.double else "f32",
             "data": "synthetic",
+            "backend": (a.backend if use_dist else None),
+            "rccl_ranks": (dist.get_world_size() if use_dist and a.backend == "nccl" else 0),
             "config": {
                 "workload": f"{a.what} = {S} chunks x {L} scored sites (+{W} warm-up) on this rank, "
                             f"K={K}, {B} SVGD particles; full inner step (param map, HIP fwd+bwd, "
                             f"all-reduce, chain rule, SVGD update)",
                 "name": a.config,
+                **data_stats,
                 "K": K, "particles": B, "chunks_per_gpu": S, "chunks_total": S_total, "chunk_size": L, "overlap": W,
                 "scaling_note": ("strong scaling: the total number of chunk rows is fixed and sharded over the ranks"
                                  if a.strong else
@@ -409,6 +523,10 @@ def main():
         }
         if ranks_identical is not None:
             out["ranks_identical_after_timed_loop"] = ranks_identical
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if os.environ.get("PHK_LIB"):  # developer A/B builds: say so in the line
+            out["PHK_LIB"] = os.environ["PHK_LIB"]
         if not a.no_cpu_baseline and world == 1:  # the CPU leg (and the parity figure it yields) runs at N = 1 only
             # GPU ll of a bounded sample, then the oracle on the same sample (also the parity figure)
             with torch.no_grad():

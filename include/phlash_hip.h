@@ -142,6 +142,10 @@ int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, 
  * empty): sequences [0, first) of the launch are swept serially, the rest by segments (R_sweep lanes
  * per sequence, seeds from a beta scan with R_scan) at the same time.  first = 0: not hybrid. */
 int phk_get_plan_hybrid(phk_handle* h, int64_t* first, int* R_sweep, int* R_scan);
+/* Force the hybrid part of a plan forced with phk_set_plan(h, 0, R, T, R_forward, 0) (first = 0: plain serial).
+ * Together the two calls reproduce what phk_get_plan + phk_get_plan_hybrid report, so that one rank's tuned
+ * plan can be installed on its peers (the reference's GPUs all run the same kernel, gpu.py:386-438). */
+int phk_set_plan_hybrid(phk_handle* h, int64_t first, int R_sweep, int R_scan);
 /* The scaled forward state is brought back to [0.5,1) by an exact power of two after every nrm-th
  * site (1, 2 or 4; 0 = library default).  nrm = 1 is the reference's per-site normalisation
  * (hmm.py:77-79); larger intervals do the same arithmetic with fewer rescales and are safe while

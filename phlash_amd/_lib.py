@@ -41,6 +41,7 @@ SIGNATURES = {
     "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),
     "phk_get_plan": (_i, [_vp, _ip, _ip, _ip, _ip, _ip]),
     "phk_get_plan_hybrid": (_i, [_vp, ctypes.POINTER(ctypes.c_int64), _ip, _ip]),
+    "phk_set_plan_hybrid": (_i, [_vp, _i64, _i, _i]),
     "phk_set_workspace_limit": (_i, [_vp, _i64]),
     "phk_workspace_bytes": (_i64, [_vp]),
     "phk_get_slab": (_i, [_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),

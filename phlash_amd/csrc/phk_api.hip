@@ -787,6 +787,20 @@ int phk_set_plan(phk_handle* h, int segmented, int R, int T, int R_forward, int 
     return PHK_OK;
 }
 
+int phk_set_plan_hybrid(phk_handle* h, int64_t first, int R_sweep, int R_scan) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (!h->has_forced_plan || h->forced_plan.segmented)
+        return fail(PHK_EINVAL, "phk_set_plan_hybrid extends a forced serial plan: call phk_set_plan(h, 0, R, T, R_forward, 0) first");
+    if (first < 0) return fail(PHK_EINVAL, "first must be >= 0");
+    if (first > 0 && (!valid_Rs(h, R_sweep) || !valid_T(h->K, R_sweep, h->forced_plan.T) || !valid_Rf(h, R_scan)))
+        return fail(PHK_EINVAL, "hybrid plan needs a valid R_sweep and R_scan for K=%d (got %d, %d)", h->K, R_sweep, R_scan);
+    if (first > 0 && R_scan == 16 && !dense_scan_ok(h)) return fail(PHK_EINVAL, "R_scan=16 (dense hom-run scan) needs K=16, float32, rescale interval 4");
+    h->forced_plan.hybrid_first = first;
+    h->forced_plan.R3 = first > 0 ? R_sweep : 0;
+    h->forced_plan.R2 = first > 0 ? R_scan : 0;
+    return PHK_OK;
+}
+
 int phk_get_plan(phk_handle* h, int* segmented, int* R, int* T, int* R_forward, int* R_scan) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     const Plan& p = h->last_plan;

@@ -100,6 +100,15 @@ class HipEngine:
     def set_plan(self, segmented: int = -1, R: int = 0, T: int = 8, R_forward: int = 0, R_scan: int = 0):
         _lib.check(_lib.load().phk_set_plan(self._h, int(segmented), int(R), int(T), int(R_forward), int(R_scan)))
 
+    def install_plan(self, plan: dict):
+        """Force exactly the plan another handle's ``get_plan`` reported (e.g. rank 0's tuned plan on every rank)."""
+        if plan["segmented"]:
+            self.set_plan(1, plan["R"], plan["T"], plan["R_forward"], plan["R_scan"])
+            return
+        self.set_plan(0, plan["R"], plan["T"], plan["R_forward"], 0)
+        _lib.check(_lib.load().phk_set_plan_hybrid(self._h, int(plan.get("hybrid_first", 0)),
+                                                   int(plan.get("R_segment_sweep", 0)), int(plan.get("R_scan", 0))))
+
     def get_plan(self) -> dict:
         v = [ctypes.c_int() for _ in range(5)]
         _lib.check(_lib.load().phk_get_plan(self._h, *(ctypes.byref(x) for x in v)))

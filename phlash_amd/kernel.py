@@ -255,19 +255,27 @@ class PSMCKernel:
         in the same device-to-host copy (one synchronisation instead of two) and is left in
         ``self.also_value`` (float).  Raises AssertionError if a chunk index was out of range (gpu.py:197-199)."""
         self.also_value = None
-        if collective and self._flags is not None:
+        if collective and self._flags is None:
+            # nothing travelled in an all-reduce since the last check: deciding from the local device word
+            # here would be exactly the rank-local decision this mode exists to rule out
+            raise RuntimeError("check_rescaling(collective=True) without a preceding sharded evaluation "
+                               "(parallel.sharded_loglik_sum / take_flags_into): no reduced flags to read")
+        under = bad = 0.0
+        if self._flags is not None:
+            # flags that a sharded evaluation moved off the device word (take_flags_async clears it there):
+            # they count for a plain check as well, or an underflow seen by that evaluation would be lost
             if also is not None:
                 both = torch.cat([self._flags.reshape(2), also.reshape(1).to(self._flags.dtype)]).cpu()  # synchronises
                 under, bad, self.also_value = (float(v) for v in both)
             else:
                 under, bad = (float(v) for v in self._flags.cpu())  # synchronises
             self._flags = None
-            assert bad == 0, f"a chunk index was outside [0, N={self.N})"
-            risk = under > 0
-        else:
-            risk = self._eng.underflow_risk()
-            if also is not None:
-                self.also_value = float(also)
+        elif also is not None:
+            self.also_value = float(also)
+        assert bad == 0, f"a chunk index was outside [0, N={self.N})"
+        risk = under > 0
+        if not collective:
+            risk = self._eng.underflow_risk() or risk  # evaluations that did not go through take_flags_into
         if risk:
             warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
             self._eng.set_rescale_interval(1)

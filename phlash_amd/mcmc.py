@@ -91,13 +91,18 @@ def _join_process_group() -> int:
         raise RuntimeError("no HIP device visible: phlash_amd.fit needs an MI355X (there is no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if dist.is_available() and dist.is_initialized():
-        if dist.get_world_size() > 1 and "LOCAL_RANK" in os.environ:
-            torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        # the caller set the group up and with it chose a device (one visible GPU per rank, several gloo
+        # ranks on one GPU, ...): respect that choice
         return torch.cuda.current_device()
     if world > 1:
         if "RANK" not in os.environ:
             raise RuntimeError("WORLD_SIZE > 1 but RANK is not set: launch with torchrun (one process per GPU)")
         local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            if ndev != 1:
+                raise RuntimeError(f"LOCAL_RANK={local} but only {ndev} HIP devices are visible to this process")
+            local = 0  # the launcher bound one GPU per rank (HIP_VISIBLE_DEVICES): it is device 0 here
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

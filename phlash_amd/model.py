@@ -43,10 +43,12 @@ class _LogPriorHip(torch.autograd.Function):
 
         from . import _lib
 
+        # (decided from ctx: grad mode is off in here, so a .contiguous() copy no longer requires grad)
+        need_grad = ctx.needs_input_grad[0]
         x = x.contiguous()
         B = x.shape[0]
         val = torch.empty(B, dtype=F64, device=x.device)
-        grad = torch.empty_like(x) if x.requires_grad else None
+        grad = torch.empty_like(x) if need_grad else None
         _lib.check(_lib.load().phk_log_prior(x.device.index, int(P), float(alpha), float(beta), x.data_ptr(), B,
                                              val.data_ptr(), grad.data_ptr() if grad is not None else None,
                                              ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))

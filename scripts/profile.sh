@@ -5,7 +5,9 @@
 # with PHK_DETERMINISTIC=1 (static plan, no tuner launches), so that every dispatch of a kernel name is
 # the same launch and the per-dispatch averages are per-launch figures of the bench loop.
 set -u
-TAG=${1:-r02}; MODE=${2:-trace}; shift 2 || true
+TAG=${1:-r03}; MODE=${2:-trace}
+[ $# -gt 0 ] && shift; [ $# -gt 0 ] && shift
+case "$MODE" in trace|full) ;; *) echo "usage: scripts/profile.sh <tag> <trace|full> [bench args...] (got mode '$MODE')" >&2; exit 2;; esac
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -13,6 +15,8 @@ export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
+RC=$?
+if [ $RC -ne 0 ]; then echo "bench.py failed under rocprofv3 (rc $RC); tail of $OUT/trace.log:" >&2; tail -n 20 "$OUT/trace.log" >&2; exit $RC; fi
 if [ "$MODE" = full ]; then
   export PHK_DETERMINISTIC=1
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -104,3 +104,21 @@ def test_no_shipped_kernel_mixes_agpr_copies_with_scratch():
                     bad.append((os.path.basename(f), cur["name"], cur["AGPRs"], cur["ScratchSize [bytes/lane]"]))
     assert n >= 500, n
     assert not bad, bad
+
+
+def test_bench_plain_multi_gpu_form_fails_loudly_without_gpus():
+    """``python bench.py --gpus 2`` (no torchrun) starts its own rank processes; with no GPU visible every rank
+    exits with a message and the launcher hands the failure on (non-zero, no JSON line, no hang).  The positive
+    path runs on the GPU box (tests/test_multirank_gpu.py)."""
+    import subprocess
+    import sys
+
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert p.stderr.count("no HIP device visible") == 2 and "rank exit codes [1, 1]" in p.stderr

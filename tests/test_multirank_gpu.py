@@ -74,6 +74,66 @@ def test_two_ranks_reproduce_one(tmp_path, shard, scenario):
         assert two[0]["nrm_calls"] == two[1]["nrm_calls"] == []
 
 
+def test_eight_ranks_reproduce_one(tmp_path):
+    """World size 8 on the real kernels (gloo, all ranks on the one GPU): 8 chunk rows -> one row per rank, a
+    minibatch of 4 rows -> ranks whose share of a minibatch is empty, one held-out row -> seven ranks without a
+    held-out row (they contribute zeros to the ELPD all-reduce and still take the same branches)."""
+    one = _launch(1, str(tmp_path / "w1"), "chunks", "plain")[0]
+    eight = _launch(8, str(tmp_path / "w8"), "chunks", "plain", timeout=900)
+    for r in range(8):
+        for key in ("c", "t", "rho"):
+            np.testing.assert_allclose(eight[r][key], one[key], rtol=1e-9, atol=1e-12, err_msg=f"rank {r} {key}")
+        assert eight[r]["nrm_calls"] == []
+
+
+def _plain_bench(args, timeout=900):
+    """``python bench.py --gpus N ...`` exactly as the driver types it: no torchrun, no rank environment."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout  # ONE JSON line on stdout, nothing else
+    return json.loads(lines[0])
+
+
+def test_bench_plain_form_self_launches_two_ranks():
+    """The form that exited with an error in round 2: plain ``python bench.py --gpus 2`` starts its own rank
+    processes (before touching the GPU), relays rank 0's line and exits 0."""
+    line = _plain_bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--backend", "gloo", "--particles", "12",
+                         "--chunks", "40", "--chunk-size", "4000", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak" and line["backend"] == "gloo"
+    assert line["ranks_identical_after_timed_loop"] is True
+    pr = line["per_rank"]
+    assert len(pr["plan"]) == 2 and len(set(pr["plan"])) == 1, pr  # rank 0's plan was installed on both
+    assert len(pr["ms_per_step"]["all"]) == 2 and pr["ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
+    assert 0 < line["config"]["het_rate"] < 0.2 and 0 < line["config"]["all_hom_word16_frac"] < 1
+
+
+def test_bench_cfg3_eight_ranks_gloo_tiny():
+    """cfg3's code path (fixed total of chunk rows sharded over the ranks, AFS term in the step) at world size 8,
+    tiny shapes: 40 rows -> 5 per rank (625 at full size)."""
+    line = _plain_bench(["--gpus", "8", "--config", "cfg3", "--steps", "2", "--warmup", "2", "--backend", "gloo",
+                         "--particles", "6", "--chunks", "40", "--chunk-size", "2000", "--overlap", "100",
+                         "--no-cpu-baseline"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["chunks_per_gpu"] == 5
+    assert line["config"]["chunks_total"] == 40 and line["ranks_identical_after_timed_loop"] is True
+    assert len(line["per_rank"]["plan"]) == 8
+
+
+def test_bench_torchrun_form_world1_rccl():
+    """The torchrun form at world size 1 initialises RCCL (backend "nccl") on the one GPU of the box."""
+    port = str(_free_port())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--steps", "2", "--warmup", "1", "--particles", "12", "--chunks", "40", "--chunk-size", "4000",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+
+
 def test_bench_two_ranks_gloo(tmp_path):
     """bench.py's own step (param map -> kernels -> all-reduce -> chain rule -> SVGD) with two ranks on
     the real kernels, tiny shapes; bench.py reports whether the replicated particles are identical on all
