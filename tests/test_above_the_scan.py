@@ -1,0 +1,273 @@
+"""Everything ABOVE the scan -- particle -> PSMCParams, the prior, the SVGD/AMSGrad update, the AFS functionals --
+against the oracle directly.
+
+Round 2 compared the HIP kernels of these rows with the product's own torch code on the device; that is a
+self-comparison.  Here the GPU tests call the C ABI (``phk_param_map``, ``phk_log_prior``, ``phk_svgd_step``)
+through ``ctypes`` -- not through ``phlash_amd/params.py`` / ``svgd.py`` / ``model.py`` -- and compare with
+``oracle/psmc_numpy.py`` (loop-form restatement of params.py:33-127, transition.py:9-85, size_history.py:123-193,
+model.py:11-21), ``oracle/psmc_torch.py`` (autograd of the same, for Jacobians), ``oracle/svgd_numpy.py``
+(loop-form blackjax 1.2.5 ``svgd`` + optax 0.2.6 ``amsgrad``) and ``oracle/afs_numpy.py`` (numerical integration
+and a lineage-count Markov chain instead of the closed forms).  The rows stay *parity unpinned* (no JAX here, no
+numeric vectors in the reference's tests); what these tests establish is agreement with an independent statement.
+The CPU half checks the product's CPU-testable definitions against the same oracles.
+"""
+
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+import oracle.afs_numpy as oafs
+import oracle.psmc_numpy as o
+import oracle.psmc_torch as ot
+import oracle.svgd_numpy as osv
+
+torch = pytest.importorskip("torch")
+
+PATTERNS = {16: "14*1+1*2", 32: "30*1+1*2", 64: "4+25*2+4+6"}
+
+
+def _population(K, B, seed, sigma=1.0, theta=1e-2, rho=2e-2):
+    """default init + N(0, sigma I) noise in the unconstrained space (mcmc.py:186-195), from the oracle's inverse map"""
+    pat = PATTERNS[K]
+    P = len(o.parse_pattern(pat))
+    x0 = o.particle_from_linear(pat, 1e-4, 15.0, np.ones(P), theta, rho)
+    rng = np.random.default_rng(seed)
+    return pat, P, x0[None] + rng.normal(size=(B, P + 3)) * math.sqrt(sigma)
+
+
+def _epoch_of_state(pat):
+    return np.array([e for e, w in enumerate(o.parse_pattern(pat)) for _ in range(w)], dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: the product's definitions against the independent oracles
+# ------------------------------------------------------------------------------------------------
+def _random_eta(seed, M=10):
+    rng = np.random.default_rng(seed)
+    log_dt, log_c = rng.normal(size=(2, M))  # the reference's fixture, tests/test_size_history.py:14-22
+    t = np.exp(log_dt).cumsum()
+    t[0] = 0.0
+    return t, np.exp(log_c)
+
+
+@pytest.mark.parametrize("n", [2, 3, 10, 20])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_etjj_etbl_W_against_quadrature_and_lineage_chain(n, seed):
+    """size_history.py:212-226, 350-369 for NON-constant size histories: the product's closed forms against
+    scipy quadrature (etjj) and against the lineage-count Markov chain with Fu's subtending probabilities (etbl,
+    which involves no W matrix), n = 20 being cfg3's sample size."""
+    from phlash_amd.size_history import SizeHistory, _W_matrix
+
+    t, c = _random_eta(seed)
+    eta = SizeHistory(t=torch.tensor(t), c=torch.tensor(c))
+    np.testing.assert_allclose(eta.etjj(n).numpy(), oafs.etjj_quad(t, c, n), rtol=1e-11)
+    np.testing.assert_allclose(eta.etbl(n).numpy(), oafs.etbl_markov(t, c, n), rtol=1e-9)
+    np.testing.assert_allclose(_W_matrix(n), oafs.W_matrix(n), rtol=0, atol=0)
+    # and the oracle itself against the closed forms the reference's tests hold (test_size_history.py:57-70)
+    k = np.arange(2, n + 1)
+    np.testing.assert_allclose(oafs.etjj_quad([0.0], [1.0], n), 2 / k / (k - 1), rtol=1e-11)
+    np.testing.assert_allclose(oafs.etbl_markov([0.0], [1.0], n), 2 / np.arange(1, n), rtol=1e-9)
+
+
+def test_afs_term_against_oracle_for_sampled_particles():
+    """model.py:58-68 at cfg3's n = 20 with the default transform (fold, then BWS binning: mcmc.py:110-114), for
+    size histories drawn like SVGD particles (not constant)."""
+    from phlash_amd.afs import bws_transform, fold_transform
+    from phlash_amd.model import afs_term
+    from phlash_amd.params import MCMCParams
+
+    pat, P, X = _population(16, 5, seed=4)
+    afs = 1e5 / np.arange(1, 20, dtype=np.float64)  # bench.py's cfg3 spectrum
+    T1 = fold_transform(20)
+    T = bws_transform(T1 @ afs) @ T1
+    init = MCMCParams.from_linear(pat, 1e-4, 15.0, np.ones(P), 1e-2, 2e-2)
+    dm = init.from_flat(torch.tensor(X)).to_dm()
+    got = afs_term(dm, afs, T).numpy()
+    got_id = afs_term(dm, afs).numpy()
+    for b in range(X.shape[0]):
+        d = o.particle_to_dm(X[b], pat, 1e-2)
+        np.testing.assert_allclose(got[b], oafs.afs_term(d.t, d.c, afs, T), rtol=1e-10)
+        np.testing.assert_allclose(got_id[b], oafs.afs_term(d.t, d.c, afs), rtol=1e-10)
+
+
+@pytest.mark.parametrize("B,D", [(1, 4), (2, 3), (7, 5), (12, 18)])
+def test_svgd_torch_definition_against_loop_oracle(B, D):
+    """phlash_amd/svgd.py (the CPU-testable definition) against the loop-form restatement of blackjax.svgd +
+    optax.amsgrad: particles, both moments, the running maximum and the length scale over consecutive steps."""
+    from phlash_amd import svgd
+
+    rng = np.random.default_rng(B * 10 + D)
+    x = rng.normal(size=(B, D))
+    a, b = svgd.init(torch.tensor(x)), osv.State(x)
+    for it in range(4):
+        g = rng.normal(size=(B, D)) * (1 + it)
+        a = svgd.step_torch(a, torch.tensor(g), 0.1)
+        b = osv.step(b, g, 0.1)
+        np.testing.assert_allclose(a.particles.numpy(), b.particles, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(a.mu.numpy(), b.mu, rtol=1e-12, atol=1e-16)
+        np.testing.assert_allclose(a.nu.numpy(), b.nu, rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(a.nu_max.numpy(), b.nu_max, rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(float(a.length_scale), b.length_scale, rtol=1e-12)
+        assert a.count == b.count == it + 1
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the C ABI against the oracles
+# ------------------------------------------------------------------------------------------------
+def _lib():
+    from phlash_amd import _lib as L
+
+    return L, L.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _row_scaled(got, want):
+    """max over rows of |got - want| / max|row of want| for [..., 7, K] parameter blocks"""
+    scale = np.abs(want).max(-1, keepdims=True)
+    return float((np.abs(got - want) / np.where(scale > 0, scale, 1.0)).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_phk_param_map_values_against_numpy_oracle(K):
+    """``phk_param_map`` (particle -> [7, K] block, one launch) against ``from_dm(particle_to_dm(x))`` of the numpy
+    oracle, sigma = 1 populations.  Entries are compared relative to the largest entry of their row (b_j and the
+    diagonal are differences of O(1) quantities: transition.py:58, 60-67)."""
+    L, lib = _lib()
+    pat, P, X = _population(K, 24, seed=K)
+    x = torch.tensor(X, device="cuda")
+    params = torch.empty((X.shape[0], 7, K), dtype=torch.float64, device="cuda")
+    ep = _epoch_of_state(pat)
+    L.check(lib.phk_param_map(0, K, P, ep.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1e-2, x.data_ptr(), X.shape[0],
+                              params.data_ptr(), None, _stream()))
+    got = params.cpu().numpy()
+    want = np.stack([o.from_dm(o.particle_to_dm(xb, pat, 1e-2)).stack() for xb in X])
+    err = _row_scaled(got, want)
+    print(f"K={K}: param map vs numpy oracle, row-scaled max error {err:.3e}")
+    assert err < 1e-11  # measured 0.9-2.3e-12 (CPU definition vs the same oracle: the v row, a ratio of products)
+    # structural zeros / ones of params.py:44-55
+    assert (got[:, 0, -1] == 0).all() and (got[:, 2, -1] == 0).all() and (got[:, 3, 0] == 0).all() and (got[:, 3, 1] == 1).all()
+    # the well-conditioned rows (emissions, pi, v) also element-wise
+    np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=5e-10, atol=1e-300)  # measured 7e-11 (pi: differences of survival values)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_phk_param_map_jacobian_against_oracle_autograd(K):
+    """The Jacobian ``phk_param_map`` returns ([B, 7K, P+3], dual numbers in the kernel) against autograd of the
+    oracle's torch restatement (``oracle/psmc_torch.py``), as Jacobian-vector products with random tangents and
+    as vector-Jacobian products with random cotangents."""
+    L, lib = _lib()
+    B = 6
+    pat, P, X = _population(K, B, seed=100 + K)
+    x = torch.tensor(X, device="cuda")
+    params = torch.empty((B, 7, K), dtype=torch.float64, device="cuda")
+    jac = torch.empty((B, 7 * K, P + 3), dtype=torch.float64, device="cuda")
+    ep = _epoch_of_state(pat)
+    L.check(lib.phk_param_map(0, K, P, ep.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1e-2, x.data_ptr(), B,
+                              params.data_ptr(), jac.data_ptr(), _stream()))
+    J = jac.cpu().numpy().reshape(B, 7, K, P + 3)
+    rng = np.random.default_rng(K)
+    worst_jvp = worst_vjp = 0.0
+    for b in range(B):
+        xb = torch.tensor(X[b], requires_grad=True)
+        Jo = torch.autograd.functional.jacobian(lambda z: ot.particle_to_params(z, pat, 1e-2), xb).numpy()  # [7, K, P+3]
+        tan = rng.normal(size=P + 3)
+        worst_jvp = max(worst_jvp, _row_scaled(J[b] @ tan, Jo @ tan))
+        cot = rng.normal(size=(7, K))
+        g, go = np.einsum("rk,rkd->d", cot, J[b]), np.einsum("rk,rkd->d", cot, Jo)
+        worst_vjp = max(worst_vjp, float(np.abs(g - go).max() / np.abs(go).max()))
+    print(f"K={K}: Jacobian vs oracle autograd, JVP row-scaled {worst_jvp:.3e}, VJP {worst_vjp:.3e}")
+    assert worst_jvp < 5e-10 and worst_vjp < 5e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,alpha,beta", [(15, 0.0, 0.0), (15, 1e-2, 1e-4), (31, 2.0, 0.5)])
+def test_phk_log_prior_against_numpy_oracle(P, alpha, beta):
+    """``phk_log_prior`` values against ``oracle.psmc_numpy.log_prior`` (model.py:11-21) and its gradient against
+    central finite differences of the oracle."""
+    L, lib = _lib()
+    pat = f"{P}*1"
+    rng = np.random.default_rng(P)
+    x0 = o.particle_from_linear(pat, 1e-4, 15.0, np.ones(P), 1e-2, 1e-2)
+    X = x0[None] + rng.normal(size=(33, P + 3)) * 1.5
+    x = torch.tensor(X, device="cuda")
+    val = torch.empty(X.shape[0], dtype=torch.float64, device="cuda")
+    grad = torch.empty_like(x)
+    L.check(lib.phk_log_prior(0, P, alpha, beta, x.data_ptr(), X.shape[0], val.data_ptr(), grad.data_ptr(), _stream()))
+    want = np.array([o.log_prior(xb, pat, alpha, beta) for xb in X])
+    np.testing.assert_allclose(val.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+    g = grad.cpu().numpy()
+    h = 1e-6
+    for b in range(0, X.shape[0], 4):
+        for d in range(P + 3):
+            e = np.zeros(P + 3)
+            e[d] = h
+            fd = (o.log_prior(X[b] + e, pat, alpha, beta) - o.log_prior(X[b] - e, pat, alpha, beta)) / (2 * h)
+            assert abs(g[b, d] - fd) <= 1e-7 * max(1.0, abs(fd)), (b, d, g[b, d], fd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D", [(1, 4), (2, 3), (7, 5), (20, 18), (33, 18)])
+def test_phk_svgd_step_against_loop_oracle(B, D):
+    """``phk_svgd_step`` (three launches: functional gradient + AMSGrad, pairwise distances, median) against the
+    loop-form restatement of blackjax.svgd + optax.amsgrad in ``oracle/svgd_numpy.py``, over consecutive steps."""
+    L, lib = _lib()
+    rng = np.random.default_rng(B * 100 + D)
+    X = rng.normal(size=(B, D))
+    ref = osv.State(X)
+    x = torch.tensor(X, device="cuda")
+    mu, nu, nmax = (torch.zeros_like(x) for _ in range(3))
+    h = torch.ones(1, dtype=torch.float64, device="cuda")
+    ws = torch.empty(max(B * (B - 1) // 2, 1), dtype=torch.float64, device="cuda")
+    for it in range(4):
+        G = rng.normal(size=(B, D)) * (1 + it)
+        g = torch.tensor(G, device="cuda")
+        x_out = torch.empty_like(x)
+        L.check(lib.phk_svgd_step(0, B, D, x.data_ptr(), g.data_ptr(), mu.data_ptr(), nu.data_ptr(), nmax.data_ptr(),
+                                  h.data_ptr(), h.data_ptr(), x_out.data_ptr(), ws.data_ptr(), it + 1, 0.1, 0.9, 0.999, 1e-8,
+                                  _stream()))
+        ref = osv.step(ref, G, 0.1)
+        x = x_out
+        np.testing.assert_allclose(x.cpu().numpy(), ref.particles, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(mu.cpu().numpy(), ref.mu, rtol=1e-10, atol=1e-15)
+        np.testing.assert_allclose(nu.cpu().numpy(), ref.nu, rtol=1e-10, atol=1e-17)
+        np.testing.assert_allclose(nmax.cpu().numpy(), ref.nu_max, rtol=1e-10, atol=1e-17)
+        if B > 1:
+            np.testing.assert_allclose(float(h), ref.length_scale, rtol=1e-11)
+
+
+@pytest.mark.gpu
+def test_cfg3_afs_term_on_the_gpu_against_oracle():
+    """cfg3's AFS term as ``bench.py`` evaluates it (torch float64 on the GPU, n = 20, identity transform) for a
+    population of sampled particles, against the lineage-chain oracle -- values, and the gradient with respect to
+    the particles against central finite differences of the oracle."""
+    from phlash_amd.model import afs_term
+    from phlash_amd.params import MCMCParams
+
+    pat, P, X = _population(16, 8, seed=9)
+    afs = 1e5 / np.arange(1, 20, dtype=np.float64)
+    init = MCMCParams.from_linear(pat, 1e-4, 15.0, np.ones(P), 1e-2, 2e-2)
+    xs = torch.tensor(X, device="cuda", requires_grad=True)
+    val = afs_term(init.from_flat(xs).to_dm(), afs)
+    (g,) = torch.autograd.grad(val.sum(), xs)
+
+    def oracle_val(xb):
+        d = o.particle_to_dm(xb, pat, 1e-2)
+        return oafs.afs_term(d.t, d.c, afs, etbl=oafs.W_matrix(20) @ oafs.etjj_quad(d.t, d.c, 20))
+
+    for b in range(X.shape[0]):
+        d = o.particle_to_dm(X[b], pat, 1e-2)
+        np.testing.assert_allclose(float(val[b]), oafs.afs_term(d.t, d.c, afs), rtol=1e-10)
+    for b in (0, 5):
+        for dcoord in (0, 1, 3, 9, 16):  # t_tr, c_tr coordinates (rho does not enter)
+            e = np.zeros(P + 3)
+            e[dcoord] = 1e-5
+            fd = (oracle_val(X[b] + e) - oracle_val(X[b] - e)) / 2e-5
+            assert abs(float(g[b, dcoord]) - fd) <= 1e-5 * max(1.0, abs(fd)), (b, dcoord, float(g[b, dcoord]), fd)
+    assert float(g[:, -1].abs().max()) == 0.0
