@@ -149,11 +149,13 @@ def test_phk_param_map_values_against_numpy_oracle(K):
     want = np.stack([o.from_dm(o.particle_to_dm(xb, pat, 1e-2)).stack() for xb in X])
     err = _row_scaled(got, want)
     print(f"K={K}: param map vs numpy oracle, row-scaled max error {err:.3e}")
-    assert err < 1e-11  # measured 0.9-2.3e-12 (CPU definition vs the same oracle: the v row, a ratio of products)
+    assert err < 4e-13  # measured on the MI355X: 2.2e-14 / 4.3e-14 / 8.0e-14 at K = 16 / 32 / 64 (profiles/r03_full_size_parity.txt)
     # structural zeros / ones of params.py:44-55
     assert (got[:, 0, -1] == 0).all() and (got[:, 2, -1] == 0).all() and (got[:, 3, 0] == 0).all() and (got[:, 3, 1] == 1).all()
     # the well-conditioned rows (emissions, pi, v) also element-wise
-    np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=5e-10, atol=1e-300)  # measured 7e-11 (pi: differences of survival values)
+    rel = float(np.abs(got[:, 4:] / want[:, 4:] - 1).max())
+    print(f"K={K}: emission and pi rows element-wise, max relative error {rel:.3e}")
+    assert rel < 5e-10  # pi: differences of survival values
 
 
 @pytest.mark.gpu
@@ -183,7 +185,7 @@ def test_phk_param_map_jacobian_against_oracle_autograd(K):
         g, go = np.einsum("rk,rkd->d", cot, J[b]), np.einsum("rk,rkd->d", cot, Jo)
         worst_vjp = max(worst_vjp, float(np.abs(g - go).max() / np.abs(go).max()))
     print(f"K={K}: Jacobian vs oracle autograd, JVP row-scaled {worst_jvp:.3e}, VJP {worst_vjp:.3e}")
-    assert worst_jvp < 5e-10 and worst_vjp < 5e-10
+    assert worst_jvp < 3e-13 and worst_vjp < 4e-12  # measured <= 5.4e-14 and <= 6.9e-13
 
 
 @pytest.mark.gpu
