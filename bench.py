@@ -458,12 +458,16 @@ def main():
         bwd_avg_s = bwd_ms / a.steps * 1e-3
         achieved = alg_bytes / bwd_avg_s / 1e9
         traffic = None
+        issue_floor = None  # VALU issue floor of the step from the static counter file (scripts/issue_floor.py)
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
-                if pj.get("workload") == f"K{K}_B{B}_S{S}_L{L}_W{W}_{'f64' if a.double else 'f32'}":
+                if pj.get("workload") == f"K{K}_B{B}_S{S}_L{L}_W{W}_{'f64' if a.double else 'f32'}" and a.het_rate is None and a.theta == 1e-2:
                     traffic = pj.get("bwd_kernel_hbm_bytes_per_launch")
+                    v = pj.get("valu")
+                    if v:
+                        issue_floor = (v["forward_phase_insts_valu"] + v["backward_phase_insts_valu"]) * 4 / v["simds"] / (v["clock_ghz"] * 1e6)
             except Exception:
                 traffic = None
         flops = 48.0 * K * B * S * L  # fwd 12K + re-run 12K + backward 24K per site.particle
@@ -518,6 +522,12 @@ def main():
                     "achieved_tflops": flops / ((fwd_ms + bwd_ms) / a.steps * 1e-3) / 1e12,
                     "peak_tflops": FP32_PEAK_TFLOPS if not a.double else FP32_PEAK_TFLOPS / 2,
                     "algorithmic_flops_per_site_particle": 48 * K,
+                    # executed VALU instructions x 4 cycles / (1,024 SIMDs x 2.4 GHz): what the kernels' own instruction
+                    # count allows; counters from an earlier rocprofv3 --pmc pass of this command (static file)
+                    "issue_floor_ms": issue_floor,
+                    "frac_of_floor": (issue_floor / ((fwd_ms + bwd_ms) / a.steps)) if issue_floor else None,
+                    "issue_floor_source": ("profiles/pmc_summary.json (static: SQ_INSTS_VALU of an earlier profiled run of "
+                                           "this command, not collected by this process)" if issue_floor else None),
                 },
             },
         }

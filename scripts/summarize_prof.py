@@ -7,6 +7,44 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def compiler_resources():
+    """{demangled kernel name without spaces: (VGPRs, AGPRs, scratch bytes/lane, waves/SIMD, LDS bytes)} from the
+    -Rpass-analysis=kernel-resource-usage reports the Makefile leaves next to every object (csrc/build/*.o.log).
+    rocprofv3's VGPR_Count column is NOT used: on gfx950 it reports half the allocation (108 for a 215-register kernel)
+    and shows no scratch."""
+    import re
+    import subprocess
+
+    res, names = {}, []
+    for f in glob.glob(os.path.join(ROOT, "phlash_amd", "csrc", "build", "*.o.log")):
+        cur = None
+        for line in open(f):
+            m = re.search(r"remark:\s+([^:]+): (.+?) \[-Rpass", line)
+            if not m:
+                continue
+            k, v = m.group(1).strip(), m.group(2).strip()
+            if k == "Function Name":
+                cur = {}
+                res[v] = cur
+                names.append(v)
+            elif cur is not None:
+                cur[k] = v
+    if not names:
+        return {}
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    outd = {}
+    for mangled, d in zip(names, dem):
+        r = res[mangled]
+        key = d.replace("void ", "").split("(")[0].replace(" ", "")
+        outd[key] = (r.get("VGPRs"), r.get("AGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"),
+                     r.get("LDS Size [bytes/block]"))
+    return outd
+
+
+RES = compiler_resources()
 
 
 def find(pattern):
@@ -28,12 +66,11 @@ for f in find("trace/**/*kernel_trace.csv"):
         n = r.get("Kernel_Name", "")
         if "phk" in n:
             d[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-            regs[n] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
-                       r.get("Workgroup_Size"), r.get("Grid_Size"))
+            regs[n] = RES.get(n.replace("void ", "").split("(")[0].replace(" ", ""), ("?", "?", "?", "?", "?"))
     for n, v in d.items():
         v2 = v[2:] if len(v) > 4 else v
         print(f"{n[:100]}: n={len(v)} avg_ms={sum(v2) / len(v2) / 1e6:.3f} min_ms={min(v) / 1e6:.3f} max_ms={max(v) / 1e6:.3f} "
-              f"vgpr/agpr/sgpr/lds/wg/grid={regs[n]}")
+              f"compiler: vgpr/agpr/scratch B per lane/waves per SIMD/static lds={regs[n]}")
 print()
 print("== PMC counters, averaged per dispatch of each PSMC kernel ==")
 for f in find("pmc_*/**/*counter_collection.csv"):
