@@ -51,19 +51,24 @@ constexpr bool f64_sweep_ok() { return sizeof(real_t) == 4 || KK / R <= (SEG ? 8
 template <int R, int T, int NRM>
 static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
+    // variants that park part of a block in LDS (psmc_kernels.hip, sweep_parked) run as workgroups of two waves: four
+    // of them share a CU's 160 KB and a workgroup stays under the 64 KB a launch gets without asking
+    constexpr int stride = sweep_lds_stride<real_t, KK, R, T, NRM>();
+    if ((size_t)stride * nt * sizeof(real_t) > 65536) nt = 128;
+    const size_t lds = (size_t)stride * nt * sizeof(real_t);
     const int spb = nt / R;
     const dim3 block(nt);
     if (units <= 0) {  // one serial sweep per sequence
         if constexpr (f64_sweep_ok<R, false>()) {
             const dim3 grid((unsigned)((nseq + spb - 1) / spb));
-            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds_bytes(R, nt), st, a);
+            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds, st, a);
         } else {
             return hipErrorInvalidValue;
         }
     } else {  // `units` independent segments per sequence
         if constexpr (f64_sweep_ok<R, true>()) {
             const dim3 grid((unsigned)((nseq + spb - 1) / spb), (unsigned)units);
-            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds_bytes(R, nt), st, a);
+            hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds, st, a);
         } else {
             return hipErrorInvalidValue;
         }

@@ -293,7 +293,9 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, 4) &&
             valid_T(h->K, 4, 8) && valid_Rf(h, 2)) {
             p.hybrid_first = first;
-            p.R3 = 4;
+            // segment sweep: the serial sweep's own variant where that is the 8-states-per-lane float32 kernel (its
+            // block store partly in LDS: fewest instructions per site, no scratch), else 4 lanes per sequence
+            p.R3 = (!h->dbl && h->K / p.R == 8 && valid_Rs(h, p.R)) ? p.R : 4;
             p.R2 = dense_scan_ok(h) ? 16 : 2;  // (16: see adjust_hybrid, applied once the launch shape is known)
         }
     }

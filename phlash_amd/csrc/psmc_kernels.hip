@@ -55,6 +55,14 @@
 #ifndef PHK_EMIS_AHEAD
 #define PHK_EMIS_AHEAD 1  // forward kernel: emission rows requested this many sites ahead (1 or 2)
 #endif
+#ifndef PHK_SWEEP_V2
+#define PHK_SWEEP_V2 1  // backward kernel, full blocks: beta pass first (storing w = e.*beta), then the forward re-run accumulates
+#endif
+#ifndef PHK_PARK
+#define PHK_PARK 2  // PHK_SWEEP_V2 with 8 float32 states per lane: this many of a block's 8 w vectors live in LDS, not registers
+                    // (one more where the group scans cross more than two lanes: measured with the compiler's scratch report,
+                    // the smallest numbers that leave the block loop free of scratch accesses)
+#endif
 #ifndef PHK_FWD_SITE_BARRIER
 #define PHK_FWD_SITE_BARRIER 1  // scheduling barrier after every site of the forward kernel's straight-line block
 #endif
@@ -427,6 +435,29 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
             for (int h = 0; h < NP; ++h) svw[h] = svw[h] + cv;
         }
     }
+    // exclusive suffix of v.*w alone (complete, other lanes' totals included): the one scan of the adjoint side a
+    // gradient row needs (gu += a .* suf(v.*w)); pre(b.*w) only feeds the beta recursion
+    __device__ __forceinline__ void suffix_vw(const V (&w)[NP], V (&svw)[NP]) const {
+        if constexpr (!SPLIT) {
+            real tv = real(0);
+#pragma unroll
+            for (int i = 2 * NP - 1; i >= 0; --i) {
+                svw[i >> 1][i & 1] = tv;
+                if (i < SPL) tv = fma_(v[i >> 1][i & 1], w[i >> 1][i & 1], tv);
+            }
+            if constexpr (R > 1) {
+                const V cv = splat<real>(g.excl_suffix(tv));
+#pragma unroll
+                for (int h = 0; h < NP; ++h) svw[h] = svw[h] + cv;
+            }
+        } else {
+            V tv;
+            half_scans<false, true>(v, w, svw, tv);
+            const V cv = carry<false>(tv);
+#pragma unroll
+            for (int h = 0; h < NP; ++h) svw[h] = svw[h] + cv;
+        }
+    }
     // beta_prev = d.*w + pre(b.*w) + u.*suf(v.*w)
     __device__ __forceinline__ V beta_prev(int h, const V (&w)[NP], const V (&svw)[NP], const V (&pbw)[NP], const V& cb) const {
         V nb = fma2<real>(d[h], w[h], pbw[h]);
@@ -662,6 +693,11 @@ __device__ __forceinline__ int64_t checked_row(const KArgs& A, int64_t ss) {
 // (NRM = 1, the reference's schedule), which is always safe.
 constexpr int RISK_EXP_F32 = -64;
 constexpr int RISK_EXP_F64 = -600;
+// The backward kernel may run a whole checkpoint block unscaled (PHK_SWEEP_V2: both passes of a block start from the
+// checkpoint and only the block's exponent TOTAL is applied, to beta, at the block's edge), so the mass must also
+// survive a block: the forward kernel raises the same flag when a block took out more than this.
+constexpr int BLOCK_RISK_EXP_F32 = -96;
+constexpr int BLOCK_RISK_EXP_F64 = -800;
 
 constexpr double LN2 = 0.693147180559945309417232121458;
 
@@ -750,6 +786,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
+    int eb_min = 0;  // ... and any whole checkpoint block
     double llW = 0.0;
     // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
     // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
@@ -923,6 +960,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                   if constexpr (CKPT) {
                       eb_u[sq_off] = (int16_t)(E - E0);
                       eb_u += nseq;
+                      eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
                   }
                   if constexpr (T == 16) {
                       w0 = w1; w1 = w2; w2 = w3;
@@ -1010,13 +1048,15 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         if constexpr (CKPT) {
             if (active && rank == 0) *ebp = (int16_t)(E - E0);
             ebp += nseq;
+            eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
         }
       }
      }
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
-        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || !(cend > 0.0)))
+        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) ||
+         eb_min < (sizeof(real) == 4 ? BLOCK_RISK_EXP_F32 : BLOCK_RISK_EXP_F64) || !(cend > 0.0)))
         atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
@@ -1040,6 +1080,26 @@ template <typename real, int K, int R, int T, bool SEG = false>
 constexpr int bwd_waves_per_simd() {
     if (SEG && PHK_SEG_WAVES > 0 && T == 8 && (K / R) * (int)sizeof(real) <= 16) return PHK_SEG_WAVES;
     return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1;
+}
+
+// PHK_SWEEP_V2 keeps w_i = e_i .* beta_{i+1} of the T sites of a block until the forward re-run has used them.  With 8
+// float32 states per lane (K = 16 at R = 2, K = 32 at R = 4: the throughput variants) those 64 registers are what pushes
+// the kernel over its 256-VGPR budget (two waves per SIMD), and the compiler's answer is scratch inside the block loop.
+// PARKED of the T vectors therefore live in LDS instead: explicit 16-byte stores in the beta pass, loads one site ahead in
+// the forward pass, in the thread's own slice behind its emission table (no barrier: nothing is shared).
+template <typename real, int K, int R, int T, int NRM>
+constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && sizeof(real) == 4 && K / R == 8) ? PHK_PARK + (R > 2 ? 1 : 0) : 0; }
+// reals per thread of the backward kernel's LDS slice: emission table + parked vectors, the stride in 16-byte units odd
+// (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
+template <typename real, int K, int R, int T, int NRM>
+constexpr int sweep_lds_stride() {
+    using L = Lane<real, K, R>;
+    constexpr int park = sweep_parked<real, K, R, T, NRM>() * 2 * L::NP;
+    if (park == 0) return L::ETAB_STRIDE;
+    constexpr int per16 = 16 / (int)sizeof(real);
+    int n = L::ETAB_STRIDE + park;
+    if ((n / per16) % 2 == 0) n += per16;
+    return n;
 }
 
 // SEG = false: one unit per sequence sweeps all blocks (blockIdx.y == 0) and writes the gradient.
@@ -1070,7 +1130,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     L lane;
     V pi[NP];
     const real* prm = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
-    real* etab = (real*)smem_raw + (size_t)tid * L::ETAB_STRIDE;
+    constexpr int PARKN = sweep_parked<real, K, R, T, NRM>();
+    real* etab = (real*)smem_raw + (size_t)tid * sweep_lds_stride<real, K, R, T, NRM>();
+    real* const park = etab + L::ETAB_STRIDE;  // (16-byte aligned: ETAB_STRIDE is a whole number of 16-byte units)
     lane.load(prm, rank, etab, pi);
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     const real* ck = (const real*)A.ckpt;
@@ -1140,72 +1202,79 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         wcur = words[widx];
         wprev = words[widx > 0 ? widx - 1 : 0];
     }
-    for (int64_t blk = blk_hi - 1; blk >= blk_lo; --blk) {
+    // Two kinds of blocks.  Nearly all are full blocks with no warm-up boundary inside: they take a straight-line body
+    // (HOT).  The partial last block of a row and the block holding the warm-up boundary take the general body with its
+    // per-site tests.  The hot blocks run in a loop of their OWN, in runs that end where a general block or a fold of the
+    // partial sums into float64 is due: with both bodies and the fold in one loop the register allocator paid for their
+    // union on the hot path (moves and scratch reloads at the join of the paths, once per block).
+    // (kernels whose lanes own more states -- 16 in float32, 8 in float64 -- keep the general body: a block of w vectors
+    // would take them past 256 registers into AGPR copies plus scratch, the regime tests/test_layout.py keeps out)
+    constexpr bool HOT_V2 = PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * SPL * (int)sizeof(real) <= 256;
+    constexpr bool HOT_SL = !HOT_V2 && bwd_straight_line<real, K, R, T>() && bwd_waves_per_simd<real, K, R, T, SEG>() <= 2;
+    constexpr bool HOT = HOT_V2 || HOT_SL;
+    const int64_t blkW = A.W > 0 ? (A.W - 1) / T : -1;                 // block holding the warm-up boundary
+    const int64_t blk_part = (A.Ltot % T) != 0 ? nblk - 1 : -1;      // partial block (the row's last), if any
+    // block prologue: step the observation words, take the block's checkpoint (requested one block earlier) and
+    // request the next one, fetch the exponent total the forward kernel took out of the block
+    auto enter = [&](const int64_t blk, V (&al0)[NP], int& e_fwd, uint32_t& codes) {
         const int64_t t0 = blk * T;
         if ((t0 >> 4) != widx) {  // stepped into the previous word
             widx = t0 >> 4;
             wcur = wprev;
             wprev = words[widx > 0 ? widx - 1 : 0];
         }
-        V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
-        real sc[T / NRM];
 #pragma unroll
-        for (int h = 0; h < NP; ++h) al[0][h] = splat<real>(real(0));
+        for (int h = 0; h < NP; ++h) al0[h] = splat<real>(real(0));
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) L::set(al[0], i, anext[i]);
-        const int e_fwd = A.eblk[blk * nseq + seq];  // exponent total the forward kernel took out of this block
-        int e_run = 0;                               // ... and the re-run below
+        for (int i = 0; i < SPL; ++i) L::set(al0, i, anext[i]);
+        e_fwd = A.eblk[blk * nseq + seq];
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint under this block's arithmetic
             const real* src = ck + ((blk - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
             for (int i = 0; i < SPL; ++i) anext[i] = src[i];
         }
-        const uint32_t codes = wcur >> (2 * (int)(t0 & 15));
-        const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
-        if (bwd_straight_line<real, K, R, T>() && bwd_waves_per_simd<real, K, R, T, SEG>() <= 2 && ns == T && !(A.W > t0 && A.W <= t0 + T)) {
-            // full block, no warm-up boundary inside: straight-line code for all 2T site steps.
-            // re-run the block forward (bit-identical to kernel 1), keeping every alpha; the
-            // emission row of the NEXT step is always in flight while the current one computes,
-            // and a scheduling barrier after every step keeps the live ranges of its temporaries
-            // from being stretched over its neighbours (the kernel sits at the 256-VGPR budget).
-            V ec[NP];
-            lane.emis(codes & 3, ec);
+        codes = wcur >> (2 * (int)(t0 & 15));
+    };
+    // fold the partial sums into float64 (units >= 1 of the segment sweep: store them, exactly once, at their left edge)
+    auto flush = [&]() {
+        since_flush = 0;
+        if (active) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) {
-                V en[NP];
-                if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
-#pragma unroll
-                for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
-                real s;
-                e_run += lane.fwd_site(al[i + 1], ec, s, rescale_after<NRM>(i));
-                if (rescale_after<NRM>(i)) sc[i / NRM] = s;
-                if (i + 1 < T) {  // (the last forward step and the first backward step share a row)
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
+            for (int i = 0; i < SPL; ++i) {
+                if constexpr (SEG) {
+                    if (blockIdx.y > 0) {  // one flush per unit (a unit is shorter than FLUSH_SITES): plain stores
+                        part[0 * K + i] = L::get(gb, i);
+                        part[1 * K + i] = L::get(gd, i);
+                        part[2 * K + i] = L::get(gu, i);
+                        part[3 * K + i] = L::get(gv, i);
+                        part[4 * K + i] = L::get(g0, i);
+                        part[5 * K + i] = L::get(g1, i);
+                        continue;
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {   // beta is the adjoint of the forward kernel's alpha at the block end; the re-run's
-                // alpha is that times 2^(e_fwd - e_run) (0 when both kernels are the same variant)
-                const V fx = splat<real>(ldexp_(real(1), e_run - e_fwd));
-#pragma unroll
-                for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
-            }
-            // sweep it backwards
-#pragma unroll
-            for (int i = T - 1; i >= 0; --i) {
-                V en[NP];
-                if (i > 0) lane.emis((codes >> (2 * (i - 1))) & 3, en);
-                const bool SC = rescale_after<NRM>(i);
-                lane.bwd_site(al[i], al[i + 1], beta, ec, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC, gb,
-                              gd, gu, gv, g0, g1);
-                if (i > 0) {
-#pragma unroll
-                    for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                {
+                    gacc[0 * K + i] += (double)L::get(gb, i);
+                    gacc[1 * K + i] += (double)L::get(gd, i);
+                    gacc[2 * K + i] += (double)L::get(gu, i);
+                    gacc[3 * K + i] += (double)L::get(gv, i);
+                    gacc[4 * K + i] += (double)L::get(g0, i);
+                    gacc[5 * K + i] += (double)L::get(g1, i);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+        }
+#pragma unroll
+        for (int h = 0; h < NP; ++h) gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
+    };
+    int64_t blk = blk_hi - 1;
+    while (blk >= blk_lo) {
+        if (!HOT || blk == blkW || blk == blk_part) {
+            const int64_t t0 = blk * T;
+            V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
+            real sc[T / NRM];
+            int e_fwd, e_run = 0;  // exponent total of the block: forward kernel's, and the re-run's below
+            uint32_t codes;
+            enter(blk, al[0], e_fwd, codes);
+            const int ns = (int)((A.Ltot - t0) < T ? (A.Ltot - t0) : T);
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (i < ns) {
@@ -1254,38 +1323,183 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                                   gb, gd, gu, gv, g0, g1);
                 }
             }
+            if constexpr (F64ACC) {
+                since_flush += ns;
+                if ((since_flush >= FLUSH_SITES && part == nullptr) || blk == blk_lo) flush();
+            }
+            --blk;
+            continue;
         }
-        if constexpr (F64ACC) {
-            since_flush += ns;
-            // (units >= 1 of the segment sweep store their sums exactly once, at their left edge)
-            if ((since_flush >= FLUSH_SITES && part == nullptr) || blk == blk_lo) {
-                since_flush = 0;
-                if (active) {
+        if constexpr (HOT) {
+            // a run of hot blocks: down to the unit's left edge, the warm-up block or the next fold, whichever comes first
+            int64_t stop = blk_lo;
+            if (blkW >= blk_lo && blkW < blk) stop = blkW + 1;
+            if constexpr (F64ACC) {
+                if (part == nullptr) {
+                    const int64_t left = since_flush < FLUSH_SITES ? (FLUSH_SITES - since_flush + T - 1) / T : 1;
+                    if (blk - left + 1 > stop) stop = blk - left + 1;
+                }
+            }
+            const int64_t first = blk;
+            for (; blk >= stop; --blk) {
+                int e_fwd;
+                uint32_t codes;
+                if constexpr (HOT_V2) {
+                    V al0[NP];
+                    enter(blk, al0, e_fwd, codes);
+                    // Full block, no warm-up boundary inside, beta pass FIRST.  Of the four scans a site's gradient rows and
+                    // recursions need on the alpha side (pre(u.*a), suf(a): both also needed by the forward step itself) and
+                    // on the beta side (suf(v.*w): needed by gu; pre(b.*w): by the beta recursion only), the order
+                    // "re-run alpha, then sweep beta" computes the alpha-side pair twice.  Here beta is swept through the
+                    // block first, keeping w_i = e_i .* beta_{i+1} of every site in registers; the forward re-run then
+                    // accumulates all six rows as it goes and recomputes only suf(v.*w_i):
+                    //     gd += w.*a   gb += w.*suf(a)   gv += w.*pre(u.*a)   gu += a.*suf(v.*w)   g0/g1 += p.*w  (= a_next.*beta_next)
+                    // Both passes run UNSCALED from the checkpoint a_0: with a'_i = a_i 2^{-E_i} (E_i: what the forward kernel's
+                    // rescales took out before site i of the block; E_0 = 0) the adjoint of a'_i is beta_i 2^{E_i}, every product
+                    // above is unchanged, and only beta at the block's right edge needs the block total: a_T = a'_T 2^{-E_T}, so
+                    // beta'_T = beta_T 2^{-E_T} (E_T = e_fwd <= 0 as recorded; the forward kernel flags blocks whose total would
+                    // leave the float range).
+                    {
+                        const V fx = splat<real>(ldexp_(real(1), -e_fwd));
 #pragma unroll
-                    for (int i = 0; i < SPL; ++i) {
-                        if constexpr (SEG) {
-                            if (blockIdx.y > 0) {  // one flush per unit (a unit is shorter than FLUSH_SITES): plain stores
-                                part[0 * K + i] = L::get(gb, i);
-                                part[1 * K + i] = L::get(gd, i);
-                                part[2 * K + i] = L::get(gu, i);
-                                part[3 * K + i] = L::get(gv, i);
-                                part[4 * K + i] = L::get(g0, i);
-                                part[5 * K + i] = L::get(g1, i);
-                                continue;
+                        for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
+                    }
+                    // w[i] of site i: sites [T - PARKN, T) in LDS (produced first by the beta pass, used last by the forward
+                    // pass: the longest lifetimes), the others in registers
+                    constexpr int NREG = T - PARKN;
+                    V w[NREG > 0 ? NREG : 1][NP];
+                    V ec[NP];
+                    lane.emis((codes >> (2 * (T - 1))) & 3, ec);
+#pragma unroll
+                    for (int i = T - 1; i >= 0; --i) {
+                        V en[NP];
+                        if (i > 0) lane.emis((codes >> (2 * (i - 1))) & 3, en);
+                        V wi[NP];
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) wi[h] = beta[h] * ec[h];
+                        if (i >= NREG) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) *(V*)(park + ((i - NREG) * NP + h) * 2) = wi[h];
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) w[i][h] = wi[h];
+                        }
+                        V svw[NP], pbw[NP], cb;
+                        lane.scans_adj(wi, svw, pbw, cb);
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) beta[h] = lane.beta_prev(h, wi, svw, pbw, cb);
+                        if (i > 0) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    V a[NP];
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) a[h] = al0[h];
+                    lane.emis(codes & 3, ec);
+                    V wc[NP];  // w of the current site; a parked one is requested one site ahead
+                    if (NREG > 0) {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) wc[h] = w[0][h];
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) wc[h] = *(const V*)(park + h * 2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+                        V en[NP], wn[NP];
+                        if (i + 1 < T) {
+                            lane.emis((codes >> (2 * (i + 1))) & 3, en);
+                            if (i + 1 >= NREG) {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) wn[h] = *(const V*)(park + ((i + 1 - NREG) * NP + h) * 2);
+                            } else {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) wn[h] = w[i + 1 < NREG ? i + 1 : 0][h];
                             }
                         }
-                        {
-                            gacc[0 * K + i] += (double)L::get(gb, i);
-                            gacc[1 * K + i] += (double)L::get(gd, i);
-                            gacc[2 * K + i] += (double)L::get(gu, i);
-                            gacc[3 * K + i] += (double)L::get(gv, i);
-                            gacc[4 * K + i] += (double)L::get(g0, i);
-                            gacc[5 * K + i] += (double)L::get(g1, i);
+                        const int code = (codes >> (2 * i)) & 3;
+                        const V f1 = splat<real>(code == 1 ? real(1) : real(0));
+                        const V f0 = splat<real>(code == 0 ? real(1) : real(0));
+                        V pre[NP], suf[NP], svw[NP];
+                        lane.scans(a, pre, suf);
+                        lane.suffix_vw(wc, svw);
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) {
+                            gd[h] = fma2<real>(wc[h], a[h], gd[h]);
+                            gb[h] = fma2<real>(wc[h], suf[h], gb[h]);
+                            gv[h] = fma2<real>(wc[h], pre[h], gv[h]);
+                            gu[h] = fma2<real>(a[h], svw[h], gu[h]);
+                            V t = lane.d[h] * a[h];
+                            t = fma2<real>(lane.v[h], pre[h], t);
+                            t = fma2<real>(lane.b[h], suf[h], t);
+                            const V m = t * wc[h];
+                            g1[h] = fma2<real>(f1, m, g1[h]);
+                            g0[h] = fma2<real>(f0, m, g0[h]);
+                            if (i + 1 < T) a[h] = t * ec[h];
                         }
+                        if (i + 1 < T) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) {
+                                ec[h] = en[h];
+                                wc[h] = wn[h];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    V al[T + 1][NP];
+                    real sc[T / NRM];
+                    int e_run = 0;
+                    enter(blk, al[0], e_fwd, codes);
+                    // full block, no warm-up boundary inside: straight-line code for all 2T site steps.
+                    // re-run the block forward (bit-identical to kernel 1), keeping every alpha; the
+                    // emission row of the NEXT step is always in flight while the current one computes,
+                    // and a scheduling barrier after every step keeps the live ranges of its temporaries
+                    // from being stretched over its neighbours (the kernel sits at the 256-VGPR budget).
+                    V ec[NP];
+                    lane.emis(codes & 3, ec);
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+                        V en[NP];
+                        if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) al[i + 1][h] = al[i][h];
+                        real s;
+                        e_run += lane.fwd_site(al[i + 1], ec, s, rescale_after<NRM>(i));
+                        if (rescale_after<NRM>(i)) sc[i / NRM] = s;
+                        if (i + 1 < T) {  // (the last forward step and the first backward step share a row)
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    {   // beta is the adjoint of the forward kernel's alpha at the block end; the re-run's
+                        // alpha is that times 2^(e_fwd - e_run) (0 when both kernels are the same variant)
+                        const V fx = splat<real>(ldexp_(real(1), e_run - e_fwd));
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
+                    }
+                    // sweep it backwards
+#pragma unroll
+                    for (int i = T - 1; i >= 0; --i) {
+                        V en[NP];
+                        if (i > 0) lane.emis((codes >> (2 * (i - 1))) & 3, en);
+                        const bool SC = rescale_after<NRM>(i);
+                        lane.bwd_site(al[i], al[i + 1], beta, ec, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC, gb,
+                                      gd, gu, gv, g0, g1);
+                        if (i > 0) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) ec[h] = en[h];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-#pragma unroll
-                for (int h = 0; h < NP; ++h) gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
+            }
+            if constexpr (F64ACC) {
+                since_flush += (int)(first - blk) * T;
+                if ((since_flush >= FLUSH_SITES && part == nullptr) || blk < blk_lo) flush();
             }
         }
     }
