@@ -63,6 +63,9 @@
                     // (one more where the group scans cross more than two lanes: measured with the compiler's scratch report,
                     // the smallest numbers that leave the block loop free of scratch accesses)
 #endif
+#ifndef PHK_DS_FIRST
+#define PHK_DS_FIRST 0  // beta-first body: ask the scheduler to issue a site's LDS reads (next emission row, next parked w) before its arithmetic
+#endif
 #ifndef PHK_FWD_SITE_BARRIER
 #define PHK_FWD_SITE_BARRIER 1  // scheduling barrier after every site of the forward kernel's straight-line block
 #endif
@@ -1194,10 +1197,13 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     // observation words, one word ahead of the (descending) block that needs it
     int64_t widx = -1;
     uint32_t wcur = 0, wprev = 0;
+    int e_next = 0;  // block exponent, requested one block ahead like the checkpoint (the beta-first body needs it first thing)
     if (blk_hi > blk_lo) {
         const real* src = ck + ((blk_hi - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) anext[i] = src[i];
+        e_next = A.eblk[(blk_hi - 1) * nseq + seq];
+
         widx = ((blk_hi - 1) * T) >> 4;
         wcur = words[widx];
         wprev = words[widx > 0 ? widx - 1 : 0];
@@ -1227,11 +1233,12 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         for (int h = 0; h < NP; ++h) al0[h] = splat<real>(real(0));
 #pragma unroll
         for (int i = 0; i < SPL; ++i) L::set(al0, i, anext[i]);
-        e_fwd = A.eblk[blk * nseq + seq];
-        if (blk > blk_lo) {  // prefetch the previous block's checkpoint under this block's arithmetic
+        e_fwd = e_next;
+        if (blk > blk_lo) {  // prefetch the previous block's checkpoint and exponent under this block's arithmetic
             const real* src = ck + ((blk - 1) * nseq + seq) * K + rank * SPL;
 #pragma unroll
             for (int i = 0; i < SPL; ++i) anext[i] = src[i];
+            e_next = A.eblk[(blk - 1) * nseq + seq];
         }
         codes = wcur >> (2 * (int)(t0 & 15));
     };
@@ -1392,6 +1399,10 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #pragma unroll
                             for (int h = 0; h < NP; ++h) ec[h] = en[h];
                         }
+#if PHK_DS_FIRST
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 400, 0);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     V a[NP];
@@ -1446,6 +1457,10 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                                 wc[h] = wn[h];
                             }
                         }
+#if PHK_DS_FIRST
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 400, 0);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
