@@ -740,6 +740,9 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 #ifndef PHK_DENSE16
 #define PHK_DENSE16 1  // A/B: 0 = no M_h^16 step
 #endif
+#ifndef PHK_DENSE_RESCALE_SITES
+#define PHK_DENSE_RESCALE_SITES 64  // dense hom-run steps: rescale once this many hom sites have gone by without one (8: after every step)
+#endif
 #ifndef PHK_FWD_LEAN
 #define PHK_FWD_LEAN 1  // A/B: 0 = lean piece loops in the one-state-per-lane kernels only (1: in every forward kernel and beta scan)
 #endif
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
     int eb_min = 0;  // ... and any whole checkpoint block
+    int hom_run = 0;  // dense kernels: hom sites stepped over since the last rescale
     double llW = 0.0;
     // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
     // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
@@ -842,22 +846,35 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // into eblk as ever; the sweep re-runs blocks in its own scaling and corrects beta by 2^(e_run - e_fwd).
     auto dense_block = [&](const uint32_t codes) {
         if constexpr (DENSE) {
+            // A rescale costs as much as the dense step itself (sum butterfly, exponent, multiply: ~90 of ~240 dependent
+            // cycles), and a hom site takes little mass away: along a run of dense steps the state is rescaled once per
+            // PHK_DENSE_RESCALE_SITES sites.  Blocks in between record an exponent of 0; power-of-two scales round
+            // nothing, so the checkpoints and the log-likelihood are the same bits times a power of two.
             if (T == 16 && PHK_DENSE16 && __all(codes == 0u)) {
                 a[0][0] = dense16(a[0][0], lane.D16);
-                const int ex = lane.rescale(a);
-                E += ex;
-                ex_min = ex < ex_min ? ex : ex_min;
+                hom_run += 16;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    const int ex = lane.rescale(a);
+                    E += ex;
+                    ex_min = ex < ex_min ? ex : ex_min;
+                }
                 return;
             }
 #pragma unroll
             for (int h8 = 0; h8 < T / 8; ++h8) {
                 if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
                     a[0][0] = dense16(a[0][0], lane.D8);
-                    const int ex = lane.rescale(a);
-                    E += ex;
-                    ex_min = ex < ex_min ? ex : ex_min;
+                    hom_run += 8;
+                    if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                        hom_run = 0;
+                        const int ex = lane.rescale(a);
+                        E += ex;
+                        ex_min = ex < ex_min ? ex : ex_min;
+                    }
                     continue;
                 }
+                hom_run = 0;  // (the groups of four below end in a rescale each)
 #pragma unroll
                 for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
                     const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
@@ -1599,6 +1616,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     for (int i = 0; i < SPL; ++i) L::set(beta, i, real(1));
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     int F = 0;
+    int hom_run = 0;  // dense kernel: hom sites stepped over since the last rescale
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
     const int nw = (int)((A.Ltot + 15) / 16);
     const int seg_words = (int)(seg_sites >> 4);  // segments are whole words (SEG_SITES = 512)
@@ -1632,18 +1650,27 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     // M_h^2 steps where every sequence of the wave is hom over the sites they cover (see fwd_kernel)
     auto dense_word = [&](const uint32_t codes) {
         if constexpr (DENSE) {
-            if (PHK_DENSE16 && __all(codes == 0u)) {
+            if (PHK_DENSE16 && __all(codes == 0u)) {  // (one rescale per PHK_DENSE_RESCALE_SITES hom sites: see fwd_kernel)
                 beta[0][0] = dense16(beta[0][0], lane.D16);
-                F += lane.rescale(beta);
+                hom_run += 16;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    F += lane.rescale(beta);
+                }
                 return;
             }
 #pragma unroll
             for (int h8 = 1; h8 >= 0; --h8) {
                 if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
                     beta[0][0] = dense16(beta[0][0], lane.D8);
-                    F += lane.rescale(beta);
+                    hom_run += 8;
+                    if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                        hom_run = 0;
+                        F += lane.rescale(beta);
+                    }
                     continue;
                 }
+                hom_run = 0;
 #pragma unroll
                 for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
                     const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
