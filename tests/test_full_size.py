@@ -326,8 +326,15 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     eng.set_deterministic(True)  # the static rule picks exactly that plan for this shape
     ll_r, g_r = eng.run(P, inds, W, grad=True)
     plan = eng.get_plan()
-    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 4, plan
-    assert torch.equal(ll_r, ll_d) and torch.equal(g_r, g_d)
+    # (segment sweep by the serial sweep's own 8-states-per-lane kernel since round 3: phk_api.hip, static_plan)
+    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 2, plan
+    assert torch.equal(ll_r, ll_d)  # (same forward kernel; the gradients come from different segment-sweep variants)
+    monkeypatch.setenv("PHK_HYBRID", "2:1:32768:2:16")
+    eng.set_deterministic(False)
+    eng.set_autotune(False)
+    ll_d2, g_d2 = eng.run(P, inds, W, grad=True)
+    monkeypatch.delenv("PHK_HYBRID")
+    assert torch.equal(ll_r, ll_d2) and torch.equal(g_r, g_d2)  # the static plan, forced by hand: the same bits
     eng.set_deterministic(False)
     eng.set_autotune(False)
     eng.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
@@ -336,7 +343,7 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     np.testing.assert_allclose(ll.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
     sub, chunks = [0, 40, 65, 66, 99], [0, 267, 268, 499]  # sequence 32768 = particle 65, chunk 268
     np.testing.assert_allclose(ll_d.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
-    for name, l_, gg in (("hybrid", ll, g), ("hybrid, dense scan", ll_d, g_d), ("serial", ll_s, g_s)):
+    for name, l_, gg in (("hybrid", ll, g), ("hybrid, dense scan", ll_d, g_d), ("static plan", ll_r, g_r), ("serial", ll_s, g_s)):
         _oracle_sample(l_, gg, P, data, sub, chunks, W, False, f"cfg2 full batch, {name}")
 
 

@@ -54,9 +54,11 @@ def _launch(world, out, shard, scenario, timeout=600):
 def test_two_ranks_reproduce_one(tmp_path, shard, scenario):
     one = _launch(1, str(tmp_path / "w1"), shard, scenario)[0]
     two = _launch(2, str(tmp_path / "w2"), shard, scenario)
-    # float64 kernels (plain): sums are re-associated by the sharding, nothing else; float32 kernels after
-    # the switch to per-site rescaling are per-sequence deterministic as well (no dense hom-run steps)
-    tol = dict(rtol=1e-9, atol=1e-12)
+    # float64 kernels (plain): the sharding re-associates sums and a rank with fewer sequences may run another kernel
+    # variant (lanes per sequence), i.e. 1e-14 differences in the gradients, which 12 AMSGrad-normalised SVGD
+    # iterations amplify to at most 2.5e-9 here (measured); float32 kernels after the switch to per-site
+    # rescaling are per-sequence deterministic as well (no dense hom-run steps)
+    tol = dict(rtol=2e-8, atol=1e-11)
     for r in range(2):
         for key in ("c", "t", "rho"):
             np.testing.assert_allclose(two[r][key], one[key], err_msg=f"rank {r} {key}", **tol)
@@ -82,7 +84,7 @@ def test_eight_ranks_reproduce_one(tmp_path):
     eight = _launch(8, str(tmp_path / "w8"), "chunks", "plain", timeout=900)
     for r in range(8):
         for key in ("c", "t", "rho"):
-            np.testing.assert_allclose(eight[r][key], one[key], rtol=1e-9, atol=1e-12, err_msg=f"rank {r} {key}")
+            np.testing.assert_allclose(eight[r][key], one[key], rtol=2e-8, atol=1e-11, err_msg=f"rank {r} {key}")
         assert eight[r]["nrm_calls"] == []
 
 
