@@ -59,9 +59,9 @@
 #define PHK_SWEEP_V2 1  // backward kernel, full blocks: beta pass first (storing w = e.*beta), then the forward re-run accumulates
 #endif
 #ifndef PHK_PARK
-#define PHK_PARK 2  // PHK_SWEEP_V2 with 8 float32 states per lane: this many of a block's 8 w vectors live in LDS, not registers
-                    // (one more where the group scans cross more than two lanes: measured with the compiler's scratch report,
-                    // the smallest numbers that leave the block loop free of scratch accesses)
+#define PHK_PARK 3  // PHK_SWEEP_V2 with 8 float32 states per lane: this many of a block's 8 w vectors live in LDS, not registers
+                    // (2 leave the block loop of the R = 2 kernel free of scratch accesses, the R = 4 kernel needs 3; 3 is
+                    // also 0.2 ms faster than 2 at cfg2: profiles/r03_ab_experiments.txt)
 #endif
 #ifndef PHK_DS_FIRST
 #define PHK_DS_FIRST 0  // beta-first body: ask the scheduler to issue a site's LDS reads (next emission row, next parked w) before its arithmetic
@@ -1108,7 +1108,7 @@ constexpr int bwd_waves_per_simd() {
 // PARKED of the T vectors therefore live in LDS instead: explicit 16-byte stores in the beta pass, loads one site ahead in
 // the forward pass, in the thread's own slice behind its emission table (no barrier: nothing is shared).
 template <typename real, int K, int R, int T, int NRM>
-constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && sizeof(real) == 4 && K / R == 8) ? PHK_PARK + (R > 2 ? 1 : 0) : 0; }
+constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && sizeof(real) == 4 && K / R == 8) ? PHK_PARK : 0; }
 // reals per thread of the backward kernel's LDS slice: emission table + parked vectors, the stride in 16-byte units odd
 // (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
 template <typename real, int K, int R, int T, int NRM>
