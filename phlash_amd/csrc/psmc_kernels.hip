@@ -1102,13 +1102,14 @@ constexpr int bwd_waves_per_simd() {
     return (T * (K / R) * (int)sizeof(real) <= 256) ? 2 : 1;
 }
 
-// PHK_SWEEP_V2 keeps w_i = e_i .* beta_{i+1} of the T sites of a block until the forward re-run has used them.  With 8
-// float32 states per lane (K = 16 at R = 2, K = 32 at R = 4: the throughput variants) those 64 registers are what pushes
+// PHK_SWEEP_V2 keeps w_i = e_i .* beta_{i+1} of the T sites of a block until the forward re-run has used them.  With 32
+// bytes of state per lane (8 float32 states: K = 16 at R = 2, K = 32 at R = 4, the throughput variants; or 4 float64
+// states) those 64 registers are what pushes
 // the kernel over its 256-VGPR budget (two waves per SIMD), and the compiler's answer is scratch inside the block loop.
 // PARKED of the T vectors therefore live in LDS instead: explicit 16-byte stores in the beta pass, loads one site ahead in
 // the forward pass, in the thread's own slice behind its emission table (no barrier: nothing is shared).
 template <typename real, int K, int R, int T, int NRM>
-constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && sizeof(real) == 4 && K / R == 8) ? PHK_PARK : 0; }
+constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && (K / R) * (int)sizeof(real) == 32) ? PHK_PARK : 0; }
 // reals per thread of the backward kernel's LDS slice: emission table + parked vectors, the stride in 16-byte units odd
 // (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
 template <typename real, int K, int R, int T, int NRM>
