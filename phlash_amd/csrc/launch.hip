@@ -1,11 +1,18 @@
-// One translation unit per (real, K): compiled with -DPHK_REAL=float|double -DPHK_K=<K>
-// -DPHK_SUFFIX=f32_16 ... so that the variants build in parallel.  Dispatches (R, T) to the
-// template instantiations of psmc_kernels.hip.
+// Two translation units per (real, K): compiled with -DPHK_REAL=float|double -DPHK_K=<K> -DPHK_SUFFIX=f32_16 ... and
+// -DPHK_PART=1 (forward kernel) or -DPHK_PART=2 (beta scan, backward kernel, finalize), so
+// that the variants build in parallel and each half gets its own compiler flags (see the Makefile).  Without PHK_PART
+// both halves are compiled into one object.  Dispatches (R, T) to the template instantiations of psmc_kernels.hip.
 #include "psmc_kernels.hip"
 
 #ifndef PHK_REAL
 #error "compile with -DPHK_REAL=float|double -DPHK_K=<K> -DPHK_SUFFIX=<tag>"
 #endif
+
+#ifndef PHK_PART
+#define PHK_PART 0
+#endif
+#define PHK_FWD_PART (PHK_PART == 0 || PHK_PART == 1)
+#define PHK_BWD_PART (PHK_PART == 0 || PHK_PART == 2)
 
 #define PHK_CAT2(a, b) a##b
 #define PHK_CAT(a, b) PHK_CAT2(a, b)
@@ -25,6 +32,7 @@ static size_t lds_bytes(int R, int nt) {
     return (size_t)raw * nt * sizeof(real_t);
 }
 
+#if PHK_FWD_PART
 template <int R, int T, int NRM>
 static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
@@ -38,6 +46,7 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     return hipGetLastError();
 }
 
+#endif
 // float64 sweeps that are not compiled (256 VGPRs + AGPR copies + scratch: see phk_api.hip, valid_Rf): the
 // serial sweep with more than 4 states per lane, the segment sweep with more than 8
 #ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile every variant
@@ -48,6 +57,7 @@ template <int R, bool SEG>
 constexpr bool f64_sweep_ok() { return sizeof(real_t) == 4 || KK / R <= (SEG ? 8 : 4); }
 #endif
 
+#if PHK_BWD_PART
 template <int R, int T, int NRM>
 static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
@@ -76,6 +86,8 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
     return hipGetLastError();
 }
 
+#endif
+#if PHK_BWD_PART
 template <int R, int NRM>
 static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
@@ -85,6 +97,7 @@ static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_
     return hipGetLastError();
 }
 
+#endif
 // T = 16 keeps 17 alpha vectors in registers: only offered where a lane owns <= 4 states.  float64 with 16
 // states per lane beyond K = 16: not compiled (more than 256 registers plus scratch: see phk_api.hip, valid_Rf)
 #ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile every variant
@@ -95,6 +108,7 @@ constexpr bool f64_fwd_ok(int R) { return sizeof(real_t) == 4 || KK / R <= 8 || 
 template <int R, int T>
 constexpr bool variant_ok() { return KK % R == 0 && KK / R <= 16 && R <= KK && (T == 8 || KK / R <= 4) && f64_fwd_ok(R); }
 
+#if PHK_FWD_PART
 template <int R, int T>
 static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     if constexpr (!variant_ok<R, T>()) {
@@ -106,10 +120,12 @@ static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t
         return hipErrorInvalidValue;
     }
 }
+#endif
 // float64 with more than 4 states per lane: not compiled (256 VGPRs + AGPR copies + scratch; see phk_api.hip, valid_Rb)
 template <int R, int T>
 constexpr bool bwd_variant_ok() { return variant_ok<R, T>() && (f64_sweep_ok<R, false>() || f64_sweep_ok<R, true>()); }
 
+#if PHK_BWD_PART
 template <int R, int T>
 static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
     if constexpr (!bwd_variant_ok<R, T>()) {
@@ -121,6 +137,8 @@ static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t
         return hipErrorInvalidValue;
     }
 }
+#endif
+#if PHK_BWD_PART
 template <int R>
 static hipError_t bscan_r(int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
     if constexpr (!variant_ok<R, 8>()) {
@@ -133,12 +151,16 @@ static hipError_t bscan_r(int nrm, const KArgs& a, int64_t seg_sites, void* bseg
     }
 }
 
+#endif
+#if PHK_FWD_PART
 template <int R>
 static hipError_t fwd_r(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     if (T == 8) return fwd_rt<R, 8>(nrm, ckpt, a, nt, st);
     if (T == 16) return fwd_rt<R, 16>(nrm, ckpt, a, nt, st);
     return hipErrorInvalidValue;
 }
+#endif
+#if PHK_BWD_PART
 template <int R>
 static hipError_t bwd_r(int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
     if (T == 8) return bwd_rt<R, 8>(nrm, a, units, nt, st);
@@ -146,6 +168,8 @@ static hipError_t bwd_r(int T, int nrm, const KArgs& a, int units, int nt, hipSt
     return hipErrorInvalidValue;
 }
 
+#endif
+#if PHK_FWD_PART
 hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     switch (R) {
         case 1: return fwd_r<1>(T, nrm, ckpt, a, nt, st);
@@ -156,6 +180,8 @@ hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, co
     }
     return hipErrorInvalidValue;
 }
+#endif
+#if PHK_BWD_PART
 hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, int nrm, const KArgs& a, int units, int nt, hipStream_t st) {
     switch (R) {
         case 1: return bwd_r<1>(T, nrm, a, units, nt, st);
@@ -166,6 +192,8 @@ hipError_t PHK_CAT(launch_bwd_, PHK_SUFFIX)(int R, int T, int nrm, const KArgs& 
     }
     return hipErrorInvalidValue;
 }
+#endif
+#if PHK_BWD_PART
 hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg,
                                               int nt, hipStream_t st) {
     switch (R) {
@@ -177,10 +205,13 @@ hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, in
     }
     return hipErrorInvalidValue;
 }
+#endif
+#if PHK_BWD_PART
 hipError_t PHK_CAT(launch_finalize_, PHK_SUFFIX)(const KArgs& a, int units, hipStream_t st) {
     const int64_t n = ((a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin) * KK;
     hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, KK, units);
     return hipGetLastError();
 }
 
+#endif
 }  // namespace phk

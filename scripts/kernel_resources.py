@@ -16,10 +16,13 @@ def main():
     real, K = sys.argv[1], sys.argv[2]
     extra = sys.argv[3:]
     ctype = {"f32": "float", "f64": "double"}[real]
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-           f"-DPHK_REAL={ctype}", f"-DPHK_K={K}", f"-DPHK_SUFFIX={real}_{K}", "-Rpass-analysis=kernel-resource-usage",
-           "-c", os.path.join(ROOT, "phlash_amd", "csrc", "launch.hip"), "-o", "/dev/null"] + extra
-    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    err = ""
+    for part, sched in ((1, []), (2, [])):  # the Makefile's two halves
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+               f"-DPHK_REAL={ctype}", f"-DPHK_K={K}", f"-DPHK_SUFFIX={real}_{K}", f"-DPHK_PART={part}",
+               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(ROOT, "phlash_amd", "csrc", "launch.hip"),
+               "-o", "/dev/null"] + sched + extra
+        err += subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], {}
     for line in err.splitlines():
         m = re.search(r"remark:\s+([^:]+): (.+?) \[-Rpass", line)
