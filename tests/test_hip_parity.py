@@ -408,7 +408,7 @@ def test_random_shapes_against_the_oracle(seed):
     if het == 0.5 and not dbl:
         # half the sites heterozygous is so far from any model here that the u / v gradients are
         # sums cancelling to 1e-6 of their terms: every variant agrees with the others to 1e-5 and
-        # the float64 kernels with the oracle to 5e-10, i.e. float32 keeps 1e-1 (scripts/diag_fuzz.py).
+        # the float64 kernels with the oracle to 5e-10, i.e. float32 keeps 1e-1 (seen with scripts/fuzz.sh).
         # Such data only exercise float64.
         het = 0.1
     data = (rng.uniform(size=(N, L)) < het).astype(np.int8)
@@ -589,7 +589,7 @@ def test_dense_hom_run_operators_f32(T, rng):
     inds = np.array([0, 1, 2, 3, 4, 5, 1])
     # the oracle is fed the float32-rounded parameter block: on the all-hom row |ll| is ~5 and the
     # rounding of the INPUTS alone moves it by 2e-5 relative -- in every float32 kernel, the
-    # reference's included (scripts/diag_allhom.py) -- which is not what this test is about
+    # reference's included (DESIGN.md section 3, f32 accuracy notes) -- which is not what this test is about
     P32 = P.astype(np.float32).astype(np.float64)
     for W in (0, 3, 4, 64, 515, L - 700):
         ll_ref, g_ref = cport.batch(P32, data, inds, W)
