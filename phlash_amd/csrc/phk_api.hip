@@ -152,6 +152,7 @@ struct phk_handle {
     hipStream_t side = nullptr;  // second stream of the segmented plan
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
+    int poison = 0;  // diagnostic: fill the scratch buffers with this byte before every launch sequence (PHK_POISON=255: NaN patterns)
     std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch since the last timing query
     int n_launches = 0;          // launches recorded since the last query
     int n_last = 0;              // ... of which by the last call
@@ -659,6 +660,7 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     else h->ws_limit = (int64_t)32 << 30;
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
     if (const char* env = std::getenv("PHK_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
+    if (const char* env = std::getenv("PHK_POISON")) h->poison = std::atoi(env);
     if (h->risk.ensure(sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, sizeof(int)) != hipSuccess) {
         delete h;
         return fail(PHK_ENOMEM, "could not allocate the underflow flag");
@@ -1082,6 +1084,18 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         for (int64_t s0 = 0; s0 < S; s0 += Ss) {
             const int64_t ns = std::min(Ss, S - s0);
             const phk::KArgs a = make_args(b0, nb, s0, ns);
+            if (h->poison) {
+                // diagnostic (environment PHK_POISON=<byte>, e.g. 255 = NaN patterns): fill every scratch buffer with that byte before every
+                // launch sequence, so that a kernel reading what no kernel of this launch sequence wrote shows up as
+                // NaN whatever ran before (an earlier call, an earlier slab of this call)
+                int bit = 0;  // PHK_POISON_MASK (default all): bit i selects the i-th buffer of this list
+                const char* menv = std::getenv("PHK_POISON_MASK");
+                const int mask = menv ? std::atoi(menv) : 0x1ff;
+                for (DevBuf* b : {&h->ckpt, &h->aux, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->part, &h->gacc}) {
+                    if (b->p && ((mask >> bit) & 1)) HIP_TRY(hipMemsetAsync(b->p, h->poison & 0xFF, b->cap, st));
+                    ++bit;
+                }
+            }
             hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
             if (h->profiling) {
                 while ((int)h->ev.size() < 3 * (h->n_launches + 1)) {

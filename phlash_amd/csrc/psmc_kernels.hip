@@ -765,6 +765,15 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
     const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
+    // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
+    // not run: lane groups without a sequence repeat the last sequence's work and, in the lean piece loops, its
+    // stores -- harmless inside a wave that also holds the real group (same wave votes, hence the same dense /
+    // structured steps, the same rescales, the same bits to the same addresses), but a wave made of repeats only
+    // votes among copies of ONE sequence, takes dense steps and rescales where the real group's wave does not, and its
+    // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
+    // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
+    // checkpoints of one scaling and exponents of the other).
+    if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
@@ -1588,6 +1597,15 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
     const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
+    // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
+    // not run: lane groups without a sequence repeat the last sequence's work and, in the lean piece loops, its
+    // stores -- harmless inside a wave that also holds the real group (same wave votes, hence the same dense /
+    // structured steps, the same rescales, the same bits to the same addresses), but a wave made of repeats only
+    // votes among copies of ONE sequence, takes dense steps and rescales where the real group's wave does not, and its
+    // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
+    // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
+    // checkpoints of one scaling and exponents of the other).
+    if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same

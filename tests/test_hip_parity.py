@@ -728,3 +728,35 @@ def test_hybrid_plan_matches_the_oracle(dbl, rng, monkeypatch):
     monkeypatch.delenv("PHK_HYBRID")
     ll, g = _run(eng, P, inds, 0)
     assert "hybrid_first" not in eng.get_plan()
+
+
+@pytest.mark.parametrize("S,T", [(3, 16), (1, 8), (5, 8), (2, 16)])
+def test_last_sequence_of_a_partly_filled_workgroup(S, T):
+    """A launch whose last workgroup of the one-state-per-lane forward kernel / beta scan has waves with no sequence at
+    all (here every launch: 1-5 sequences, 16 per workgroup).  Lane groups without a sequence repeat the last
+    sequence's work; a wave made of such repeats only used to run, vote among copies of one sequence, take dense steps
+    and rescales where the real group's wave did not, and race its differently scaled checkpoints and block exponents
+    against the real ones -- found by the round-3 fuzz soak (seed 1055 of the dense test: 5 of 6 fresh processes
+    returned a wrong gradient for the LAST sequence once the dense steps rescaled only every 64 hom sites).  Such
+    waves now leave at once.  Repeated with fresh kernel objects because the outcome of a race depends on timing."""
+    rng = np.random.default_rng(1055)
+    L, W = 512, 64
+    data = (rng.uniform(size=(S, L)) < 0.005).astype(np.int8)
+    data[:, 100:130] = -1
+    P = _params(16, 1, 1, seed=1055)
+    Pin = P.astype(np.float32).astype(np.float64)
+    inds = np.arange(S)
+    ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+    for rep in range(8):
+        for form in (0, 1):
+            eng = _engine(16, data, False)
+            eng.set_autotune(False)
+            eng.set_rescale_interval(4)
+            if form == 0:  # dense forward kernel, serial sweep
+                eng.set_plan(0, R=4 if T == 16 else 2, T=T, R_forward=16, R_scan=0)
+            else:  # dense forward kernel beside the dense beta scan, segment sweep
+                eng.set_plan(1, R=4 if T == 16 else 2, T=T, R_forward=16, R_scan=16)
+            ll, g = _run(eng, P, inds, W)
+            np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
+            worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
+            assert worst < 1.0, (rep, form, worst)
