@@ -773,7 +773,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
     // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
     // checkpoints of one scaling and exponents of the other).
+#ifndef PHK_KEEP_IDLE_WAVES  // (diagnostic builds define it to show that the regression test catches the race)
     if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
+#endif
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
@@ -1605,7 +1607,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
     // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
     // checkpoints of one scaling and exponents of the other).
+#ifndef PHK_KEEP_IDLE_WAVES  // (diagnostic builds define it to show that the regression test catches the race)
     if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
+#endif
     // Which sequence a lane group works on is free (sequences are independent; everything stored is
     // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
     // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
