@@ -63,6 +63,9 @@
                     // (2 leave the block loop of the R = 2 kernel free of scratch accesses, the R = 4 kernel needs 3; 3 is
                     // also 0.2 ms faster than 2 at cfg2: profiles/r03_ab_experiments.txt)
 #endif
+#ifndef PHK_EXP_NO_CKPT_STORE
+#define PHK_EXP_NO_CKPT_STORE 0  // timing-only diagnostic builds: the forward kernel does not store its checkpoints (results are wrong)
+#endif
 #ifndef PHK_DS_FIRST
 #define PHK_DS_FIRST 0  // beta-first body: ask the scheduler to issue a site's LDS reads (next emission row, next parked w) before its arithmetic
 #endif
@@ -291,6 +294,19 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     static constexpr int SLOT(int i) { return 2 * PH(i) + HF(i); }    // position in an emission-table row
     static __device__ __forceinline__ real get(const V (&x)[NP], int i) { return x[PH(i)][HF(i)]; }
     static __device__ __forceinline__ void set(V (&x)[NP], int i, real val) { x[PH(i)][HF(i)] = val; }
+
+    // Checkpoint layout in HBM: [block][K/4 pieces][sequence][4 states].  One store instruction of a wave (one 16-byte
+    // piece per lane) then writes 64 consecutive pieces = 1 KB of consecutive addresses whatever the kernel's lanes per
+    // sequence, and so does a load of the backward kernel.  (Rounds 1-2 kept [block][sequence][K]: a lane's 64 bytes
+    // contiguous, so that every dwordx4 store of a wave touched all 32 lines of a 4 KB region in 16-byte pieces; with
+    // more than one forward wave per SIMD -- cfg3, cfg5 -- the forward kernel ran 25 % slower than without its
+    // stores, profiles/r03_ab_experiments.txt item 12.)
+    // ck_lane: offset of this lane's first state inside a block; state i of the lane sits at ck_lane + ck_elem(i, nseq).
+    static __device__ __forceinline__ int64_t ck_lane(int64_t nseq, int64_t seq, int rank) {
+        const int k0 = rank * SPL;
+        return ((int64_t)(k0 / 4) * nseq + seq) * 4 + (SPL < 4 ? k0 % 4 : 0);
+    }
+    static __device__ __forceinline__ int64_t ck_elem(int i, int64_t nseq) { return (int64_t)(i / 4) * nseq * 4 + (i % 4); }
 
     // p: [7,K] rows b,d,u,v,emis0,emis1,pi (gpu.py:189 stacking order); padding lanes hold zeros
     // (ones in the emission rows) so that they stay exactly 0 through every step.
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     const int blkW = A.W > 0 ? (int)((A.W - 1) / T) : -1;     // block holding the warm-up boundary
     const int iW = A.W > 0 ? (int)((A.W - 1) - (int64_t)blkW * T) : -1;  // ... after its site iW
     const int64_t ck_step = nseq * K;
-    real* ckp = (real*)A.ckpt + seq * K + rank * SPL;   // this lane's slice of the current block's checkpoint
+    real* ckp = (real*)A.ckpt + L::ck_lane(nseq, seq, rank);   // this lane's first state in the current block's checkpoint
     int16_t* ebp = A.eblk + seq;
     int32_t* esp = A.eseg + seq;
     int seg_left = 0;  // blocks until the next segment starts
@@ -945,7 +961,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // stores by every lane (lanes past the last sequence repeat its work bit for bit: same value, same address).
     constexpr bool LEAN = PPB == 1 && (DENSE ? PHK_DENSE_LEAN != 0 : (PHK_FWD_LEAN != 0 && PHK_EMIS_AHEAD < 2));
     const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K < (int64_t(1) << 31);
-    const unsigned ck_off = (unsigned)(seq * K + rank * SPL), sq_off = (unsigned)seq;
+    const unsigned ck_off = (unsigned)L::ck_lane(nseq, seq, rank), sq_off = (unsigned)seq;
+    const unsigned ck_piece = (unsigned)(nseq * 4);  // distance between the pieces of one sequence
     int blk = 0;
     for (int pc = 0; blk < nblk; pc += PPB) {
      const uint4 c0 = pnext, c1 = nx1, c2 = nx2, c3 = nx3;
@@ -981,8 +998,10 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 #pragma nounroll
               for (int bi = 0; bi < BPC; ++bi) {
                   if constexpr (CKPT) {
+#if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
-                      for (int i = 0; i < SPL; ++i) ck_u[ck_off + i] = L::get(a, i);
+                      for (int i = 0; i < SPL; ++i) ck_u[ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4)] = L::get(a, i);
+#endif
                       ck_u += ck_step;
                   }
                   const int E0 = E;
@@ -1017,7 +1036,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         if constexpr (CKPT) {
             if (active) {
 #pragma unroll
-                for (int i = 0; i < SPL; ++i) ckp[i] = L::get(a, i);
+                for (int i = 0; i < SPL; ++i) ckp[L::ck_elem(i, nseq)] = L::get(a, i);
             }
             ckp += ck_step;
         }
@@ -1203,10 +1222,10 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
             // factor on beta that does not decay along the sweep and shows up undamped in d ll/d pi
             // after the warm-up correction.  Normalise the seed against the forward kernel's own
             // alpha at this edge (its checkpoint): the identity then holds exactly where the sweep starts.
-            const real* ca = ck + (blk_hi * nseq + seq) * K + rank * SPL;
+            const real* ca = ck + blk_hi * nseq * K + L::ck_lane(nseq, seq, rank);
             real dot = real(0);
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) dot = fma_(ca[i], L::get(beta, i), dot);
+            for (int i = 0; i < SPL; ++i) dot = fma_(ca[L::ck_elem(i, nseq)], L::get(beta, i), dot);
             dot = lane.g.sum(dot);
             const V inv = splat<real>(dot > real(0) ? real(1) / dot : real(1));
 #pragma unroll
@@ -1228,9 +1247,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     uint32_t wcur = 0, wprev = 0;
     int e_next = 0;  // block exponent, requested one block ahead like the checkpoint (the beta-first body needs it first thing)
     if (blk_hi > blk_lo) {
-        const real* src = ck + ((blk_hi - 1) * nseq + seq) * K + rank * SPL;
+        const real* src = ck + (blk_hi - 1) * nseq * K + L::ck_lane(nseq, seq, rank);
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) anext[i] = src[i];
+        for (int i = 0; i < SPL; ++i) anext[i] = src[L::ck_elem(i, nseq)];
         e_next = A.eblk[(blk_hi - 1) * nseq + seq];
 
         widx = ((blk_hi - 1) * T) >> 4;
@@ -1264,9 +1283,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         for (int i = 0; i < SPL; ++i) L::set(al0, i, anext[i]);
         e_fwd = e_next;
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint and exponent under this block's arithmetic
-            const real* src = ck + ((blk - 1) * nseq + seq) * K + rank * SPL;
+            const real* src = ck + (blk - 1) * nseq * K + L::ck_lane(nseq, seq, rank);
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) anext[i] = src[i];
+            for (int i = 0; i < SPL; ++i) anext[i] = src[L::ck_elem(i, nseq)];
             e_next = A.eblk[(blk - 1) * nseq + seq];
         }
         codes = wcur >> (2 * (int)(t0 & 15));
