@@ -498,7 +498,7 @@ def main():
                                  if a.strong else
                                  f"weak scaling: every rank holds its own {S} chunk rows ({S_total} in all); "
                                  "use --config cfg3 for the fixed 5,000-row problem"),
-                "kernel_variant": {"lanes_per_sequence": R, "checkpoint_block": T,
+                "kernel_variant": {"lanes_per_sequence": R, "forward_lanes": plan.get("R_forward", R), "checkpoint_block": T,
                                    "plan": "segmented" if plan["segmented"] else ("hybrid" if plan.get("hybrid_first") else "serial"),
                                    **({"serial_sequences": plan["hybrid_first"], "segment_sweep_lanes": plan["R_segment_sweep"]}
                                       if plan.get("hybrid_first") else {})},
