@@ -466,6 +466,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     at.W = std::min<int64_t>(proto.W, tune_sites);
     Plan best;
     float best_ms = 0.f;
+    const bool verbose = std::getenv("PHK_TUNE_VERBOSE") != nullptr;  // diagnostic: the tuner's timings on stderr
     auto time_launch = [&](auto&& launch, float* ms) -> int {
         for (int rep = 0; rep < 2; ++rep) {
             HIP_TRY(hipEventRecord(e0, st));
@@ -483,11 +484,25 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         // checkpoints for any backward variant of the same T) and the fastest of each is kept
         int bf = 0, bb = 0;
         float tf = 0.f, tb = 0.f;
-        for (int R = 1; R <= 16; R <<= 1) {
+        float fms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // forward variants R = 1, 2, 4, 8, 16
+        for (int R = 1, ri = 0; R <= 16; R <<= 1, ++ri) {
             if (!valid_Rf(h, R) || !valid_T(K, R, T)) continue;
             float ms = 0.f;
             if ((rc = time_launch([&] { return l.fwd(R, T, h->nrm, want_grad, at, 256, st); }, &ms)) != PHK_OK) return rc;
+            if (verbose) std::fprintf(stderr, "phk tune: nseq %lld forward R=%d T=%d on %lld sites: %.3f ms\n", (long long)nseq, R, T, (long long)tune_sites, ms);
+            fms[ri] = ms;
             if (!bf || ms < tf) { tf = ms; bf = R; }
+        }
+        // near-ties go to the variant with fewer lanes per sequence (fewer instructions per site): on the truncated
+        // problem the checkpoint stores still land in the caches, at full length they do not, and the variant with the
+        // fewest instructions gains (K = 32, 159,000 sequences: R = 2 / 4 time 2.70 / 2.83 ms on 2,048 sites but
+        // 49 / 60 ms at full length; the plain minimum picked R = 4 in most runs)
+        for (int R = 1, ri = 0; R < bf; R <<= 1, ++ri) {
+            if (fms[ri] > 0.f && fms[ri] <= 1.08f * tf) {
+                bf = R;
+                tf = fms[ri];
+                break;
+            }
         }
         if (want_grad) {
             for (int R = 1; R <= 16; R <<= 1) {
@@ -495,6 +510,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
                 float ms = 0.f;
                 if (!h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
                 if ((rc = time_launch([&] { return l.bwd(R, T, h->nrm, at, 0, 256, st); }, &ms)) != PHK_OK) return rc;
+                if (verbose) std::fprintf(stderr, "phk tune: nseq %lld sweep   R=%d T=%d on %lld sites: %.3f ms\n", (long long)nseq, R, T, (long long)tune_sites, ms);
                 if (!bb || ms < tb) { tb = ms; bb = R; }
             }
         } else {
@@ -609,6 +625,9 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (verbose)
+        std::fprintf(stderr, "phk tune: nseq %lld grad %d -> segmented %d R %d T %d R_forward %d R_scan %d hybrid_first %lld R_sweep %d\n", (long long)nseq,
+                     (int)want_grad, best.segmented, best.R, best.T, best.R1, best.R2, (long long)best.hybrid_first, best.R3);
     h->tuned[{nseq, want_grad ? 1 : 0}] = best;
     return PHK_OK;
 }
