@@ -651,7 +651,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
 struct SeqAux {      // written by the forward kernel, read by the backward kernel
     double inv_end;  // 1 / sum(alpha) after the last site (scaled state)
     int32_t e_end;   // exponent total E after the last site: true alpha_L = alpha * 2^E
-    int32_t pad_;
+    int32_t eb_min;  // smallest exponent total of any checkpoint block of the sequence (<= 0)
 };
 
 struct KArgs {
@@ -712,11 +712,12 @@ __device__ __forceinline__ int64_t checked_row(const KArgs& A, int64_t ss) {
 // (NRM = 1, the reference's schedule), which is always safe.
 constexpr int RISK_EXP_F32 = -64;
 constexpr int RISK_EXP_F64 = -600;
-// The backward kernel may run a whole checkpoint block unscaled (PHK_SWEEP_V2: both passes of a block start from the
-// checkpoint and only the block's exponent TOTAL is applied, to beta, at the block's edge), so the mass must also
-// survive a block: the forward kernel raises the same flag when a block took out more than this.
-constexpr int BLOCK_RISK_EXP_F32 = -96;
-constexpr int BLOCK_RISK_EXP_F64 = -800;
+// The backward kernel runs a whole checkpoint block unscaled in its hot body (PHK_SWEEP_V2: both passes of a block
+// start from the checkpoint and only the block's exponent TOTAL is applied, to beta, at the block's edge).  A block out
+// of which the forward kernel took more than this many binary orders takes the general body instead (it rescales as
+// it goes): decided per block from the recorded exponent, no flag, no fallback of the whole kernel object.
+constexpr int HOT_BLOCK_MIN_EXP_F32 = -64;
+constexpr int HOT_BLOCK_MIN_EXP_F64 = -600;
 
 constexpr double LN2 = 0.693147180559945309417232121458;
 
@@ -819,8 +820,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
-    int eb_min = 0;  // ... and any whole checkpoint block
     int hom_run = 0;  // dense kernels: hom sites stepped over since the last rescale
+    int eb_min = 0;   // smallest exponent total of any checkpoint block
     double llW = 0.0;
     // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
     // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
@@ -1105,14 +1106,14 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
-        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) ||
-         eb_min < (sizeof(real) == 4 ? BLOCK_RISK_EXP_F32 : BLOCK_RISK_EXP_F64) || !(cend > 0.0)))
+        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || !(cend > 0.0)))
         atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
         if constexpr (CKPT) {
             A.aux[seq].inv_end = 1.0 / cend;
             A.aux[seq].e_end = E;
+            A.aux[seq].eb_min = eb_min;
         }
     }
 }
@@ -1320,9 +1321,15 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #pragma unroll
         for (int h = 0; h < NP; ++h) gb[h] = gd[h] = gu[h] = gv[h] = g0[h] = g1[h] = splat<real>(real(0));
     };
+    // A sequence with a block too steep for the unscaled hot body (see HOT_BLOCK_MIN_EXP) makes its whole wave take
+    // the general body for every block: decided once per wave from what the forward kernel recorded, so that the hot
+    // loop itself carries no test (a per-block test with an exit from the hot loop cost 1.6-2.9 ms at cfg2: the exit
+    // edge brought scratch accesses back into the block)
+    constexpr int HOT_MIN_EXP = sizeof(real) == 4 ? HOT_BLOCK_MIN_EXP_F32 : HOT_BLOCK_MIN_EXP_F64;
+    const bool wave_steep = HOT_V2 && __any(A.aux[seq].eb_min < HOT_MIN_EXP);
     int64_t blk = blk_hi - 1;
     while (blk >= blk_lo) {
-        if (!HOT || blk == blkW || blk == blk_part) {
+        if (!HOT || wave_steep || blk == blkW || blk == blk_part) {
             const int64_t t0 = blk * T;
             V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
             real sc[T / NRM];

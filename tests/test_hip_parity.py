@@ -391,6 +391,40 @@ def test_tiny_emissions_need_per_site_rescaling():
     assert not e4.underflow_risk()
 
 
+@pytest.mark.parametrize("dbl", [False, True])
+@pytest.mark.parametrize("plan", ["serial", "segmented"])
+def test_steep_blocks_take_the_general_body(plan, dbl):
+    """The backward kernel's hot body runs a checkpoint block of 8 sites unscaled.  Het emissions of 1e-3 everywhere
+    on runs of 8 ... 24 het sites take 2^-40 out of every group of four (no rescale finds less than 2^-64: no flag,
+    no fallback) but 2^-80 out of a block of eight: such blocks are swept by the general body, which rescales as it
+    goes, chosen per block from the exponent the forward kernel recorded.  Values and gradients against the oracle,
+    and no flag raised."""
+    K, L = 16, 1200
+    P = _params(K, 2, 1, seed=3)
+    P[:, 0, 5] = 1e-3
+    P[:, 0, 4] = 1.0 - 1e-3
+    rng = np.random.default_rng(7)
+    data = (rng.uniform(size=(3, L)) < 0.01).astype(np.int8)
+    for r in range(3):
+        for s0, n in ((40 + 7 * r, 8), (301, 16), (640 + r, 24), (1100, 9)):
+            data[r, s0:s0 + n] = 1
+    eng = _engine(K, data, dbl)
+    eng.set_autotune(False)
+    eng.set_rescale_interval(4)
+    if plan == "serial":
+        eng.set_plan(0, R=4 if dbl else 2, T=8, R_forward=2, R_scan=0)
+    else:
+        eng.set_plan(1, R=4 if dbl else 2, T=8, R_forward=2, R_scan=2)
+    inds = np.arange(3)
+    Pin = P if dbl else P.astype(np.float32).astype(np.float64)
+    for W in (0, 300):
+        ll, g = _run(eng, P, inds, W)
+        ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5)
+        assert _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, dbl) < 1.0
+    assert not eng.underflow_risk()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PHK_FUZZ_SEEDS", "120"))))
 def test_random_shapes_against_the_oracle(seed):
     """Seeded random draws over everything the launch depends on -- K, float type, particles x
