@@ -48,13 +48,14 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
 
 #endif
 // float64 sweeps that are not compiled (256 VGPRs + AGPR copies + scratch: see phk_api.hip, valid_Rf): the
-// serial sweep with more than 4 states per lane, the segment sweep with more than 8
+// serial sweep with more than 4 states per lane, the segment sweep with more than 4 (8 at K = 16, where the compiler's
+// report shows no scratch; at K = 32 the same layout came back with AGPR copies plus 20 B of scratch in round 3)
 #ifdef PHK_EXP_F64_SPL16  // diagnostic builds only (scripts/diag_fenced_variants.py): compile every variant
 template <int R, bool SEG>
 constexpr bool f64_sweep_ok() { return true; }
 #else
 template <int R, bool SEG>
-constexpr bool f64_sweep_ok() { return sizeof(real_t) == 4 || KK / R <= (SEG ? 8 : 4); }
+constexpr bool f64_sweep_ok() { return sizeof(real_t) == 4 || KK / R <= 4 || (SEG && KK == 16 && KK / R == 8); }
 #endif
 
 #if PHK_BWD_PART

@@ -207,11 +207,11 @@ bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R); }
 #else
 bool valid_Rb(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 4); }
 #endif
-// ... as the segment sweep (SEG = true instantiations: no scratch up to 8 states per lane in float64)
+// ... as the segment sweep (SEG = true instantiations: 8 states per lane in float64 at K = 16 only, see launch.hip)
 #ifdef PHK_EXP_F64_SPL16
 bool valid_Rs(const phk_handle* h, int R) { return valid_R(h->K, R); }
 #else
-bool valid_Rs(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 8); }
+bool valid_Rs(const phk_handle* h, int R) { return valid_R(h->K, R) && (!h->dbl || h->K / R <= 4 || (h->K == 16 && h->K / R == 8)); }
 #endif
 // T = 16 keeps 17 alpha vectors in registers: only compiled where a lane owns <= 4 states
 bool valid_T(int K, int R, int T) { return T == 8 || (T == 16 && K / R <= 4); }

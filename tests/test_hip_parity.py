@@ -458,7 +458,8 @@ def test_random_shapes_against_the_oracle(seed):
     mode = int(rng.integers(5))
     Rs = [r for r in (1, 2, 4, 8, 16) if r <= K and K // r <= (8 if dbl else 16)]  # forward / scan variants
     Rsw = [r for r in Rs if K // r <= 4] if dbl else Rs  # serial sweep variants (float64: <= 4 states per lane)
-    Rsg = Rs  # segment sweep variants (float64: <= 8 states per lane)
+    # segment sweep variants (float64: <= 4 states per lane, 8 at K = 16 only: launch.hip, f64_sweep_ok)
+    Rsg = [r for r in Rs if K // r <= 4 or (K == 16 and K // r == 8)] if dbl else Rs
     hybrid = None
     if mode == 4 and B * S >= 2:  # hybrid form of the serial plan with a random split (developer override)
         hybrid = f"{int(rng.choice(Rsw))}:{int(rng.choice(Rs))}:{int(rng.integers(1, B * S))}:{int(rng.choice(Rsg))}:{int(rng.choice(Rs))}"
