@@ -534,7 +534,9 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
         if (first > 0 && nseq - first > per_round / 20) {
             Plan hbest_plan;
             float hbest = 0.f;
-            const int cand[5][2] = {{4, 2}, {2, 2}, {4, 4}, {4, 16}, {2, 16}};  // (segment sweep, beta scan) lanes per sequence
+            // (segment sweep, beta scan) lanes per sequence; the static rule's choice first, and a later candidate
+            // has to beat the best so far by 2 % (the candidates' single timings scatter by about that much)
+            const int cand[5][2] = {{2, 16}, {4, 16}, {2, 2}, {4, 2}, {4, 4}};
             for (const auto& c : cand) {
                 if (!valid_Rs(h, c[0]) || !valid_T(K, c[0], 8) || !valid_Rf(h, c[1])) continue;
                 if (c[1] == 16 && !dense_scan_ok(h)) continue;
@@ -546,10 +548,12 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
                 if (c[1] == 16 && hyb.R2 != 16) continue;  // (the split cannot be a range of whole particles here)
                 float ms = 0.f;
                 if ((rc = timed(a, hyb, true, &ms)) != PHK_OK) return rc;
-                if (hbest == 0.f || ms < hbest) { hbest = ms; hbest_plan = hyb; }
+                if (verbose) std::fprintf(stderr, "phk tune: nseq %lld hybrid first %lld sweep R=%d scan R=%d at full length: %.3f ms\n", (long long)nseq, (long long)hyb.hybrid_first, hyb.R3, hyb.R2, ms);
+                if (hbest == 0.f || ms < 0.98f * hbest) { hbest = ms; hbest_plan = hyb; }
             }
             float full_ms = 0.f;  // the serial plan at full length, same conditions
             if ((rc = timed(a, best, true, &full_ms)) != PHK_OK) return rc;
+            if (verbose) std::fprintf(stderr, "phk tune: nseq %lld serial plan at full length: %.3f ms\n", (long long)nseq, full_ms);
             if (hbest > 0.f && hbest < full_ms) best = hbest_plan;
         }
     }
