@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo processes shard the chunk rows, evaluate their share
+"""The N>1 path on CPU: world_size-2 and world_size-8 gloo processes shard the chunk rows, evaluate their share
 (the oracle stands in for the GPU kernel here -- tests may use it as a checker/evaluator, the
 product never does) and combine value + gradient in ONE all-reduce.  The result must equal the
 unsharded evaluation, including a rank that owns nothing from the minibatch."""
@@ -47,7 +47,7 @@ def _worker(rank, size, port, minibatch, out):
         rng = np.random.default_rng(0)
         chunks = (rng.uniform(size=(7, 260)) < 0.06).astype(np.int8)
         mine = parallel.local_rows(len(chunks), rank, size)
-        kern = _OracleKern(chunks[mine], overlap=40)
+        kern = _OracleKern(chunks[mine] if len(mine) else chunks[:0], overlap=40)
         init = MCMCParams.from_linear("14*1+1*2", 1e-4, 15.0, np.ones(15), 1e-2, 1e-2)
         x = (init.flat[None] + 0.2 * torch.tensor(np.random.default_rng(1).normal(size=(3, 18)))).requires_grad_(True)
         pp = PSMCParams.from_dm(init.from_flat(x).to_dm())
@@ -90,13 +90,16 @@ def test_particle_sharding(tmp_path):
     np.testing.assert_allclose(got["g"], g, rtol=1e-14)
 
 
-@pytest.mark.parametrize("minibatch", [[0, 1, 2, 3, 4, 5, 6], [2, 2, 4], [5]])
-def test_sharded_equals_unsharded(tmp_path, minibatch):
+@pytest.mark.parametrize("size,minibatch", [(2, [0, 1, 2, 3, 4, 5, 6]), (2, [2, 2, 4]), (2, [5]),
+                                            (8, [0, 1, 2, 3, 4, 5, 6]), (8, [6, 6, 1])])
+def test_sharded_equals_unsharded(tmp_path, size, minibatch):
+    """World size 2, and 8 (the node the driver benchmarks): 7 chunk rows over 8 ranks leave rank 7 without a row at
+    all, and a 3-row minibatch leaves most ranks with an empty share -- they contribute zeros to the one all-reduce."""
     from oracle import cport
     from phlash_amd.params import MCMCParams, PSMCParams
 
     out = str(tmp_path / "r0.pt")
-    mp.start_processes(_worker, args=(2, _free_port(), minibatch, out), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(size, _free_port(), minibatch, out), nprocs=size, join=True, start_method="spawn")
     got = torch.load(out)
     # unsharded evaluation, same inputs
     rng = np.random.default_rng(0)
