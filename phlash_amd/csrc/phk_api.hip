@@ -386,10 +386,11 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));  // (float64 too: unit 0 of a segment sweep adds into it)
         HIP_TRY(hipEventRecord(h->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        e = l.bscan(plan.R2, h->nrm, a2, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
-        if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (hybrid, K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
+        // (forward kernel first: its 784 lone waves are to be on their SIMDs before the scan's 4,376 fill the slots)
         e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, Rf, plan.T, hipGetErrorString(e));
+        e = l.bscan(plan.R2, h->nrm, a2, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
+        if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (hybrid, K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         HIP_TRY(hipEventRecord(h->ev_fwd, st));
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fwd, 0));
@@ -418,12 +419,12 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     a.part = h->part.p;
     HIP_TRY(hipEventRecord(h->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
-    if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(h->ev_join, h->side));
     e = l.fwd(plan.R1, plan.T, h->nrm, true, a, nt, st);
     if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R1, plan.T, hipGetErrorString(e));
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
+    e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
+    if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(h->ev_join, h->side));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
     e = l.bwd(plan.R, plan.T, h->nrm, a, units, nt, st);
     if (e != hipSuccess) return fail(PHK_EHIP, "segment kernel launch (K=%d R=%d T=%d units=%d): %s", K, plan.R, plan.T, units, hipGetErrorString(e));
@@ -694,7 +695,14 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     // segmented plans lost their overlap).  Streams of another priority level get queues of their own.
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+    // LOWEST priority: what runs on the side stream (beta scan, segment sweep) is filler beside the long-lived waves of the
+    // caller's stream (forward kernel, serial sweep), which have to get their wave slots first: a forward wave that finds
+    // both slots of its SIMD taken by beta-scan waves starts a scan wave's lifetime late (forward phase 11.9 instead of
+    // 11.0 ms at cfg2 in about every other run, profiles/r03_ab_experiments.txt item 14).  PHK_SIDE_PRIO=high: round 2's
+    // choice, for A/B runs.
+    const char* sp = std::getenv("PHK_SIDE_PRIO");
+    const int side_prio = (sp && sp[0] == 'h') ? prio_greatest : prio_least;
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, side_prio) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fwd, hipEventDisableTiming) != hipSuccess) {
