@@ -214,3 +214,39 @@ def test_flag_is_read_behind_the_launch_stream():
         eng.run(Pd, di, 0, grad=False)
         assert eng.underflow_risk()  # must wait for the kernel on `side`
         assert not eng.underflow_risk()
+
+
+def test_install_plan_reproduces_another_handles_plan(monkeypatch):
+    """``phk_set_plan`` + ``phk_set_plan_hybrid`` install exactly what ``phk_get_plan`` + ``phk_get_plan_hybrid`` report
+    (bench.py hands rank 0's tuned plan to every rank this way): a second kernel object with the first one's plan
+    installed returns the same bits -- serial, hybrid (with and without the dense beta scan) and segmented plans --
+    and argument errors come back as PHK_EINVAL."""
+    from phlash_amd.engine import HipEngine
+    from phlash_amd.synth import simulate_chunks
+
+    K, B, S, L, W = 16, 3, 40, 9000, 100
+    data = simulate_chunks(K, S, L, seed=8)
+    P = _params(K, B, seed=9).cuda()
+    inds = torch.arange(S, device="cuda")
+    for spec in ("2:1:64:2:2", "2:1:80:2:16", "4:2:37:4:2", None, "segmented"):
+        a = HipEngine(K, data)
+        a.set_autotune(False)
+        if spec == "segmented":
+            a.set_plan(1, R=2, T=8, R_forward=16, R_scan=16)
+        elif spec:
+            monkeypatch.setenv("PHK_HYBRID", spec)
+        else:
+            a.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
+        ll_a, g_a = a.run(P, inds, W, grad=True)
+        monkeypatch.delenv("PHK_HYBRID", raising=False)
+        plan = a.get_plan()
+        if spec and spec != "segmented":
+            assert plan["hybrid_first"] > 0, (spec, plan)
+        b = HipEngine(K, data)
+        b.install_plan(plan)
+        ll_b, g_b = b.run(P, inds, W, grad=True)
+        assert b.get_plan() == plan, (b.get_plan(), plan)
+        assert torch.equal(ll_a, ll_b) and torch.equal(g_a, g_b), spec
+    e = HipEngine(K, data)
+    with pytest.raises(AssertionError):  # PHK_EINVAL: no forced serial plan to extend
+        e.install_plan({"segmented": 0, "R": 2, "T": 8, "R_forward": 1, "R_scan": 0, "hybrid_first": 64, "R_segment_sweep": 3})
