@@ -44,6 +44,14 @@ against the reference test it restates:
   path enumeration; reverse-mode gradient == autograd == finite differences
   (the roles of tests/test_gpu.py:27-64, tests/test_model.py:8-19)
 
+Round 3 added oracles for those rows that share no code (and, where possible, no formula) with the product,
+so that the GPU tests of the parameter map, the prior, the SVGD step and the AFS term compare the HIP kernels
+with an independent statement instead of with the product's own torch code: ``psmc_numpy.from_dm`` /
+``particle_to_dm`` / ``log_prior`` (loops), ``psmc_torch`` (autograd Jacobians), ``svgd_numpy`` (loop-form
+blackjax 1.2.5 ``svgd`` + optax 0.2.6 ``amsgrad``), ``afs_numpy`` (``etjj`` by scipy quadrature, ``etbl`` from
+the lineage-count Markov chain and Fu's subtending probabilities -- no W matrix).  Still unpinned: agreement
+with an independent restatement is not agreement with the reference.
+
 ``tests/golden/psmc_golden.npz`` (``oracle/make_golden.py``) is restatement-derived and labelled
 as such; it overlaps with the reference-captured file on the conftest inputs, where the two agree
 to 1e-13.  The SVGD / AMSGrad arithmetic of the reference lives in third-party blackjax==1.2.5 /
