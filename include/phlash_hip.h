@@ -182,6 +182,15 @@ int phk_last_timing(phk_handle* h, float* fwd_ms, float* bwd_ms, int* n_launches
  * switched on); waits once, at query time, so a timed loop needs no per-step synchronisation. */
 int phk_timing_totals(phk_handle* h, double* fwd_ms, double* bwd_ms, int* n_launches);
 
+/* Environment variables read by the library (none is needed in normal use):
+ *   PHK_AUTOTUNE=0         static plan rule instead of the timing-based tuner
+ *   PHK_DETERMINISTIC=1    as phk_set_deterministic(h, 1) for every handle
+ *   PHK_TUNE_VERBOSE=1     the tuner's timings and decision on stderr
+ *   PHK_HYBRID=R:Rf:first:R3:R2   developer override of the hybrid plan (tests)
+ *   PHK_SIDE_PRIO=high     second stream at the highest instead of the lowest priority (A/B runs)
+ *   PHK_POISON=<byte>      diagnostic: fill the scratch buffers with that byte before every launch sequence
+ *                          (255: NaN patterns); PHK_POISON_MASK selects buffers */
+
 #ifdef __cplusplus
 }
 #endif
