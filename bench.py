@@ -13,7 +13,9 @@ GPU) -> PSMCParams for every particle (HIP kernel, float64, with Jacobian) -> HI
 backward kernels over all B x S (particle, chunk) sequences -> sum over chunks -> ONE all-reduce of
 [B, 1 + 7K] across ranks (N > 1) -> chain rule to particle space -> SVGD/AMSGrad update.
 Work per step = B * S * L scored site.particles per GPU (the W warm-up sites of every chunk are
-run but not counted).
+run but not counted).  Before the W warm-up steps there is an untimed set-up: data generation, upload, and ONE step whose
+result is discarded, in which the library selects (tunes) its plan for the launch shape and torch's allocator gets its
+blocks -- so that the timed region is the same whatever --warmup is, 0 included.
 
 Workload (default, BASELINE.json configs[1], "cfg2"): 1 diploid, 3 Gb = 500 chunks x 60,000 scored
 sites (+500 warm-up), K = 16, 100 particles, float32 kernels.  With N > 1 this is WEAK scaling: every
@@ -394,16 +396,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
+    # Set-up, untimed: one step whose result is DISCARDED (the particles are not advanced), so that the library selects
+    # (tunes) its plan for this launch shape and torch's allocator has its blocks before the W warm-up steps and the K
+    # timed steps, whatever --warmup is (0 included: without it the first timed step carried ~90 ms of one-time work).
+    one_step(state)
+    if use_dist and world > 1 and a.same_plan and not a.variant:
+        # every rank tuned by timing; all ranks run the same shapes, so install rank 0's choice everywhere
+        # (otherwise the step time is the max over N independently chosen plans)
+        mine = kern._eng.get_plan()
+        keys = ("segmented", "R", "T", "R_forward", "R_scan", "hybrid_first", "R_segment_sweep")
+        pt = torch.tensor([int(mine.get(k, 0)) if rank == 0 else 0 for k in keys], dtype=torch.int64, device=dev)
+        dist.all_reduce(pt)  # = broadcast from rank 0
+        kern._eng.install_plan(dict(zip(keys, (int(v) for v in pt.cpu()))))
+    flags.zero_()  # (the set-up step's flags are not the timed loop's)
+    for _ in range(a.warmup):
         state = one_step(state)
-        if i == 0 and use_dist and world > 1 and a.same_plan and not a.variant:
-            # the first step tuned a plan on every rank by timing; all ranks run the same shapes, so install
-            # rank 0's choice everywhere (otherwise the step time is the max over N independently chosen plans)
-            mine = kern._eng.get_plan()
-            keys = ("segmented", "R", "T", "R_forward", "R_scan", "hybrid_first", "R_segment_sweep")
-            pt = torch.tensor([int(mine.get(k, 0)) if rank == 0 else 0 for k in keys], dtype=torch.int64, device=dev)
-            dist.all_reduce(pt)  # = broadcast from rank 0
-            kern._eng.install_plan(dict(zip(keys, (int(v) for v in pt.cpu()))))
     barrier()
     kern._eng.timing_totals()  # drop the warm-up steps' events
     t0 = time.perf_counter()
@@ -479,6 +486,8 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
+            "untimed_setup": "data generation, upload, one discarded step (plan selection by the library, allocator warm-up)"
+                             + (" and rank 0's plan installed on every rank" if use_dist and world > 1 and a.same_plan else ""),
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if a.strong else "weak",
