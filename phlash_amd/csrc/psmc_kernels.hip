@@ -46,6 +46,9 @@
 #ifndef PHK_SERIAL_PRIO
 #define PHK_SERIAL_PRIO 0  // s_setprio of the serial backward sweep's waves (0..3)
 #endif
+#ifndef PHK_SEG_PRIO
+#define PHK_SEG_PRIO 0  // s_setprio of the segment sweep's waves (they share SIMDs with the serial sweep's in the hybrid plan)
+#endif
 #ifndef PHK_BSCAN_PRIO
 #define PHK_BSCAN_PRIO 0  // s_setprio of the beta scan's waves (they share SIMDs with the forward kernel's)
 #endif
@@ -1170,6 +1173,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     const int tid = threadIdx.x;
 #if PHK_SERIAL_PRIO
     if constexpr (!SEG) __builtin_amdgcn_s_setprio(PHK_SERIAL_PRIO);
+#endif
+#if PHK_SEG_PRIO
+    if constexpr (SEG) __builtin_amdgcn_s_setprio(PHK_SEG_PRIO);
 #endif
     const int64_t nseq = A.B * A.S;
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
