@@ -81,7 +81,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int DEFAULT_NRM = 4;   // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
-constexpr int SEG_SITES = 512;    // sites per segment of the segmented backward
+constexpr int SEG_SITES = 512;  // sites per segment of the segmented backward
 constexpr int seg_blocks(int T) { return SEG_SITES / T; }  // 64 blocks at T = 8, 32 at T = 16
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 
