@@ -536,7 +536,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             Plan hbest_plan;
             float hbest = 0.f;
             // (segment sweep, beta scan) lanes per sequence; the static rule's choice first, and a later candidate
-            // has to beat the best so far by 2 % (the candidates' single timings scatter by about that much)
+            // has to beat the best so far by 3 % (the candidates' single timings scatter by about 2 %)
             const int cand[5][2] = {{2, 16}, {4, 16}, {2, 2}, {4, 2}, {4, 4}};
             for (const auto& c : cand) {
                 if (!valid_Rs(h, c[0]) || !valid_T(K, c[0], 8) || !valid_Rf(h, c[1])) continue;
@@ -550,7 +550,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
                 float ms = 0.f;
                 if ((rc = timed(a, hyb, true, &ms)) != PHK_OK) return rc;
                 if (verbose) std::fprintf(stderr, "phk tune: nseq %lld hybrid first %lld sweep R=%d scan R=%d at full length: %.3f ms\n", (long long)nseq, (long long)hyb.hybrid_first, hyb.R3, hyb.R2, ms);
-                if (hbest == 0.f || ms < 0.98f * hbest) { hbest = ms; hbest_plan = hyb; }
+                if (hbest == 0.f || ms < 0.97f * hbest) { hbest = ms; hbest_plan = hyb; }
             }
             float full_ms = 0.f;  // the serial plan at full length, same conditions
             if ((rc = timed(a, best, true, &full_ms)) != PHK_OK) return rc;
