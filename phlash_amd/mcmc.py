@@ -3,6 +3,12 @@
 The per-iteration step (mcmc.py:275-286) is the hot loop: particles -> PSMCParams (torch float64)
 -> HIP kernel (value + gradient, warm-up fused) -> chain rule by autograd -> SVGD/AMSGrad update.
 
+The option preamble of ``fit`` (names, defaults and the order in which they are read: ``key, niter, window_size,
+overlap, chunk_size, max_samples, num_workers, mutation_rate, truth, elpd_cutoff, afs_transform, minibatch_size,
+init, theta, t1, tM, rho_over_theta, alpha, beta, learning_rate, sigma, num_particles``) follows the reference's
+``fit`` (mcmc.py:66-176) nearly line by line ON PURPOSE: it is the option schema a drop-in has to keep.
+Everything below it (sharding, kernels, flags, the step) is this package's own.
+
 Differences from the reference, all deliberate:
 * the warm-up prefix of every chunk is evaluated inside the kernel (``overlap`` fused) instead of a
   separate JAX scan that JAX then differentiates (model.py:52-55);
