@@ -118,6 +118,7 @@ class PSMCKernel:
         if keep_host_data:
             self.host_data = data.cpu().numpy() if isinstance(data, torch.Tensor) else np.array(data, copy=True)
         self._flags = None  # [2] float64 on the device: flags of the evaluations since the last check
+        self._pinned, self._pin_turn = None, 0  # host slots of begin_check / finish_check
         self._eng = HipEngine(M, data, double_precision=double_precision, device=device)
         self.N, self.L = self._eng.N, self._eng.L
         assert 0 <= self.overlap <= self.L
@@ -277,6 +278,38 @@ class PSMCKernel:
         if not collective:
             risk = self._eng.underflow_risk() or risk  # evaluations that did not go through take_flags_into
         if risk:
+            warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
+            self._eng.set_rescale_interval(1)
+            return True
+        return False
+
+
+    def begin_check(self, also: torch.Tensor):
+        """First half of ``check_rescaling(collective=True, also=...)``: queues the copy of the reduced flags and of
+        ``also`` to pinned host memory on the current stream and returns at once, so that the caller can launch its
+        next step before it looks at this one's flags (phlash_amd.mcmc.fit does).  ``finish_check`` is the other half."""
+        if self._flags is None:
+            raise RuntimeError("begin_check without a preceding sharded evaluation (parallel.sharded_loglik_sum / "
+                               "take_flags_into): no reduced flags to read")
+        dev = torch.cat([self._flags.reshape(2), also.reshape(1).to(self._flags.dtype)])
+        self._flags = None
+        if self._pinned is None:  # two slots: a caller holds at most one check open while it begins the next
+            self._pinned = [torch.empty(3, dtype=F64).pin_memory() for _ in range(2)]
+        self._pin_turn ^= 1
+        slot = self._pinned[self._pin_turn]
+        slot.copy_(dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        return slot, done
+
+    def finish_check(self, pending) -> bool:
+        """Second half: waits for the copy ``begin_check`` queued, then decides like ``check_rescaling`` (True = the
+        step those flags belong to has to be redone, per-site rescaling is switched on; ``also_value`` is set)."""
+        slot, done = pending
+        done.synchronize()
+        under, bad, self.also_value = (float(v) for v in slot)
+        assert bad == 0, f"a chunk index was outside [0, N={self.N})"
+        if under > 0:
             warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
             self._eng.set_rescale_interval(1)
             return True

@@ -279,7 +279,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             it = tqdm.trange(niter, desc="Fitting model")
         except ImportError:
             pass
-    def grad_logp(inds):
+    def grad_logp(state, inds):
         """d log density / d particles for this minibatch [B, D]; ends in exactly one all-reduce."""
         if by_particles:
             _, g = parallel.particle_sharded_value_and_grad(
@@ -293,23 +293,59 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
         (g,) = torch.autograd.grad(lp.sum(), xs)
         return g
 
+    def step_from(st, inds):
+        """The state after one SVGD step from ``st`` on minibatch ``inds``, and the handle of its flags on their way
+        to the host.  Nothing here waits for the device."""
+        new = svgd.step(st, grad_logp(st, inds), lr)
+        return new, train_kern.begin_check(also=torch.isfinite(new.particles).all())
+
+    def step_checked(st, inds):
+        """The same with the flags read at once.  An extreme particle may need per-site rescaling (the kernel raises
+        a device flag).  The flag travelled in the step's all-reduce, so every rank reads the same value here and all
+        of them redo the step (which contains another all-reduce) or none does."""
+        new, chk = step_from(st, inds)
+        if train_kern.finish_check(chk):
+            new, chk = step_from(st, inds)
+            train_kern.finish_check(chk)
+        assert train_kern.also_value == 1.0, "particles went non-finite"  # mcmc.py:281-285
+        return new
+
+    # The flags of step i are read AFTER step i + 1 has been launched, so the host prepares a step while the device
+    # runs the one before it (one device-to-host copy per step either way; read at once, it left the GPU idle for
+    # the ~1 ms the host needs to launch the next step).  Should they ask for a redo -- once per fit at most: the
+    # switch to per-site rescaling is permanent -- step i + 1, which started from a state that does not count, is
+    # dropped and both steps are run again from the state before step i, on the minibatches already drawn.  Every
+    # rank reads the same reduced flags one step late, so all of them still take the same branch.  A callback or
+    # the ELPD gets particles whose step has been checked.
+    lag = bool(options.get("lagged_check", True)) and cb is None
+    pending = None  # (flags handle, state before that step, its minibatch): the one step not yet checked
+
+    def settle():
+        nonlocal state, pending
+        if pending is None:
+            return
+        chk, before, inds_ = pending
+        pending = None
+        if train_kern.finish_check(chk):
+            state = step_checked(before, inds_)
+        assert train_kern.also_value == 1.0, "particles went non-finite"
+
     for i in it:
         inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
-        g = grad_logp(inds)
-        # The update is launched before the host looks at anything (it does not modify `state`), and the
-        # kernel flags and the finiteness of the new particles then come back in ONE device-to-host copy.
-        # An extreme particle may need per-site rescaling (the kernel raises a device flag).  The flag
-        # travelled in the step's all-reduce, so every rank reads the same value here and all of them
-        # redo the step (which contains another all-reduce) or none does.
-        new_state = svgd.step(state, g, lr)
-        finite = torch.isfinite(new_state.particles).all()
-        if train_kern.check_rescaling(collective=True, also=finite):
-            g = grad_logp(inds)
-            new_state = svgd.step(state, g, lr)
-            train_kern.check_rescaling(collective=True, also=torch.isfinite(new_state.particles).all())
-        assert train_kern.also_value == 1.0, "particles went non-finite"  # mcmc.py:281-285
-        state = new_state
+        if not lag:
+            state = step_checked(state, inds)
+        else:
+            new_state, chk = step_from(state, inds)
+            if pending is not None and train_kern.finish_check(pending[0]):
+                _, before, inds_ = pending
+                pending = None
+                state = step_checked(step_checked(before, inds_), inds)
+            else:
+                assert pending is None or train_kern.also_value == 1.0, "particles went non-finite"
+                pending = (chk, state, inds)
+                state = new_state
         if elpd is not None and i % 10 == 0:
+            settle()
             e = elpd(state.particles)
             ema = e if ema is None else 0.9 * ema + 0.1 * e
             if best_elpd is None or ema > best_elpd[1]:
@@ -318,6 +354,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                 break
         if cb is not None:
             cb(dms(state.particles))
+    settle()
 
     out = dms(state.particles)
     t, c = out.eta.t.cpu(), out.eta.c.cpu()

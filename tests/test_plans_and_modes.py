@@ -161,6 +161,46 @@ def test_deterministic_mode_is_bit_reproducible(monkeypatch):
     assert torch.equal(r1[1], r2[1])
 
 
+@pytest.mark.parametrize("flag_at", [None, 0, 2, 5])
+def test_fit_reads_flags_one_step_late_with_the_same_result(monkeypatch, flag_at):
+    """fit() launches step i + 1 before it reads step i's flags (mcmc.py: lagged check).  The particles are the same
+    to the last bit as with the flags read after every step, also when a step reports an underflow (here: a flag
+    the device never raised, put into the hand-over of the chosen step) and is redone together with the step that
+    was launched on top of it; the switch to per-site rescaling happens once either way."""
+    from phlash_amd.data import RawContig
+    from phlash_amd.engine import HipEngine
+    from phlash_amd.mcmc import fit
+
+    rng = np.random.default_rng(2)
+    contigs = [RawContig(het_matrix=(rng.uniform(size=(1, 9000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
+               for _ in range(3)]
+    orig_take, orig_nrm = HipEngine.take_flags_async, HipEngine.set_rescale_interval
+    out = {}
+    for lagged in (False, True):
+        seen = {"n": 0, "nrm": []}
+
+        def take(self, dst, seen=seen):
+            orig_take(self, dst)
+            if seen["n"] == flag_at:
+                dst[0] = 1.0
+            seen["n"] += 1
+
+        def set_nrm(self, nrm=0, seen=seen):
+            seen["nrm"].append(int(nrm))
+            orig_nrm(self, nrm)
+
+        monkeypatch.setattr(HipEngine, "take_flags_async", take)
+        monkeypatch.setattr(HipEngine, "set_rescale_interval", set_nrm)
+        res = fit(contigs, key=11, niter=6, overlap=100, chunk_size=2900, num_particles=40, minibatch_size=3,
+                  progress=False, deterministic=True, lagged_check=lagged)
+        out[lagged] = (torch.stack([r.eta.c for r in res]), [r.rho for r in res], seen["nrm"], seen["n"])
+    assert torch.equal(out[True][0], out[False][0]) and out[True][1] == out[False][1]
+    assert out[True][2] == out[False][2] == ([] if flag_at is None else [1])
+    # evaluations: 6 steps, + the redone step, + (lagged, unless it was the last step) the one launched on top of it
+    extra = 0 if flag_at is None else 1
+    assert out[False][3] == 6 + extra and out[True][3] == 6 + extra * (1 if flag_at == 5 else 2)
+
+
 def test_out_of_range_chunk_index():
     """gpu.py:197-199 asserts 0 <= index < N on the host.  Host indices are checked the same way; indices
     that live on the device are checked by the kernels (clamped to row 0, sticky flag) and reported at
