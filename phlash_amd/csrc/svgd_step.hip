@@ -14,10 +14,11 @@
 //                        coordinate sums over i in index order and applies the AMSGrad update (float64);
 //   pair_dist_kernel   : the n (n - 1) / 2 pairwise distances of the new particles;
 //   median_kernel      : ONE workgroup: exact bucket select of the two middle order statistics, h_next.  One
-//                        workgroup reads at one CU's rate (~25 GB/s), so this is for populations of up to a
-//                        couple of hundred particles (cfg2: 100 -> 4,950 distances, ~15 us); for larger ones the
-//                        caller passes h_out = NULL and takes the median of the distance buffer with a
-//                        device-wide sort (500 particles: 124,750 distances, 284 us here against ~100 us).
+//                        workgroup reads at one CU's rate, so this is for populations of up to a
+//                        couple of hundred particles (cfg2: 100 -> 4,950 distances, 25 us; 200: the whole step
+//                        54 us against 86 with the sort); for larger ones the caller passes h_out = NULL and
+//                        takes the median of the distance buffer with a device-wide sort (500 particles:
+//                        124,750 distances, step 159 us here against 112).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -117,9 +118,10 @@ struct SelShared {
     double cand[SEL_CAP];
     unsigned long long mn, mx;
     int ncand, bucket;
-    long long k_in, below;
+    long long k_in;
     double result;
-    int done;
+    int wsum[16];  // per-wave totals of the histogram prefix
+    int cnt;
 };
 
 __device__ double select_kth(const double* __restrict__ v, int64_t n, int64_t k, SelShared& S) {
@@ -161,15 +163,35 @@ __device__ double select_kth(const double* __restrict__ v, int64_t n, int64_t k,
             }
         }
         __syncthreads();
-        if (t == 0) {
-            long long kk = k_rel;
-            int b = 0;
-            for (; b < SEL_BINS - 1; ++b) {
-                if (kk < S.hist[b]) break;
-                kk -= S.hist[b];
+        // the bucket holding rank k_rel: exclusive prefix of the histogram over the workgroup (thread t owns BPT
+        // consecutive buckets; a serial walk by one thread was 35 of this kernel's 65 us per select)
+        {
+            constexpr int BPT = SEL_BINS / 1024;
+            static_assert(SEL_BINS % 1024 == 0, "median_kernel runs 1024 threads");
+            int own = 0;
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) own += S.hist[t * BPT + i];
+            const int lane = t & 63, wv = t >> 6;
+            int inc = own;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(inc, off);
+                if (lane >= off) inc += y;
             }
-            S.bucket = b;
-            S.k_in = kk;
+            if (lane == 63) S.wsum[wv] = inc;
+            __syncthreads();
+            long long before = inc - own;
+            for (int i = 0; i < wv; ++i) before += S.wsum[i];
+            if (k_rel >= before && k_rel < before + own) {  // exactly one thread
+                long long kk = k_rel - before;
+                int bk = t * BPT;
+                for (; bk < t * BPT + BPT - 1; ++bk) {
+                    if (kk < S.hist[bk]) break;
+                    kk -= S.hist[bk];
+                }
+                S.bucket = bk;
+                S.k_in = kk;
+            }
         }
         __syncthreads();
         const int bsel = S.bucket;
@@ -237,7 +259,27 @@ __global__ __launch_bounds__(1024) void median_kernel(const double* __restrict__
     const double vlo = select_kth(v, n, lo, S);
     __syncthreads();
     double vhi = vlo;
-    if (hi != lo) vhi = select_kth(v, n, hi, S);
+    if (hi != lo) {
+        // the next order statistic without a second select: vlo again if more than lo + 1 elements are <= vlo, else
+        // the smallest element above it (distances are >= 0: their bit patterns order like their values)
+        if (threadIdx.x == 0) {
+            S.cnt = 0;
+            S.mn = ~0ull;
+        }
+        __syncthreads();
+        const unsigned long long klo = (unsigned long long)__double_as_longlong(vlo);
+        int c = 0;
+        unsigned long long nx = ~0ull;
+        for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(v[e]);
+            if (key <= klo) ++c;
+            else nx = key < nx ? key : nx;
+        }
+        atomicAdd(&S.cnt, c);
+        atomicMin(&S.mn, nx);
+        __syncthreads();
+        vhi = (int64_t)S.cnt >= hi + 1 ? vlo : __longlong_as_double((long long)S.mn);
+    }
     if (threadIdx.x == 0) {
         const double med = vlo + (vhi - vlo) * (pos - (double)lo);
         *h_out = med * med / log((double)B);

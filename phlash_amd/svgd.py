@@ -113,7 +113,7 @@ def step_hip(state: SVGDState, grad_logp: torch.Tensor, lr: float, b1=0.9, b2=0.
     return SVGDState(particles=x_out, length_scale=h_out.reshape(()), mu=mu, nu=nu, nu_max=nu_max, count=count)
 
 
-_MEDIAN_IN_KERNEL = 16384  # pairwise distances (181 particles) up to which the single-workgroup select is used
+_MEDIAN_IN_KERNEL = 32768  # pairwise distances (256 particles) up to which the single-workgroup select is used (it wins up to ~300)
 
 
 def step(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:

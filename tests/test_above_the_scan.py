@@ -245,6 +245,34 @@ def test_phk_svgd_step_against_loop_oracle(B, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,kind", [(2, "normal"), (3, "normal"), (4, "normal"), (100, "normal"), (101, "normal"),
+                                    (250, "normal"), (250, "lattice"), (120, "copies"), (256, "lattice")])
+def test_median_select_of_the_svgd_step(B, kind):
+    """The length scale the SVGD step leaves behind = median(pairwise distances)^2 / log B (the median heuristic of
+    blackjax 1.2.5, update_median_heuristic), from the single-workgroup bucket select: odd and even numbers of
+    distances, populations up to the in-kernel limit, and inputs whose distances take a handful of values only
+    (lattice points / repeated particles: buckets of thousands of equal keys, the narrowing path of the select)."""
+    from scipy.spatial.distance import pdist
+
+    from phlash_amd import svgd
+
+    rng = np.random.default_rng(B)
+    if kind == "normal":
+        X = rng.normal(size=(B, 18))
+    elif kind == "lattice":
+        X = rng.integers(0, 2, size=(B, 18)).astype(np.float64)
+    else:  # five distinct particles, repeated
+        X = rng.normal(size=(5, 18))[rng.integers(0, 5, size=B)]
+    assert B * (B - 1) // 2 <= svgd._MEDIAN_IN_KERNEL
+    x = torch.tensor(X, device="cuda")
+    st = svgd.init(x)
+    new = svgd.step_hip(st, torch.zeros_like(x), 0.0)  # lr = 0: the particles stay where they are
+    assert torch.equal(new.particles, x)
+    want = float(np.median(pdist(X))) ** 2 / math.log(B)
+    np.testing.assert_allclose(float(new.length_scale), want, rtol=1e-14, atol=0)  # (fma vs plain sums in the distances)
+
+
+@pytest.mark.gpu
 def test_cfg3_afs_term_on_the_gpu_against_oracle():
     """cfg3's AFS term as ``bench.py`` evaluates it (torch float64 on the GPU, n = 20, identity transform) for a
     population of sampled particles, against the lineage-chain oracle -- values, and the gradient with respect to
