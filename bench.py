@@ -10,8 +10,8 @@ bench.py --gpus N ...`` works as before (the ranks find their environment and ru
 
 One *step* = one pass of the hot path over one batch: B particles (unconstrained vectors on the
 GPU) -> PSMCParams for every particle (HIP kernel, float64, with Jacobian) -> HIP forward + checkpointed
-backward kernels over all B x S (particle, chunk) sequences -> sum over chunks -> ONE all-reduce of
-[B, 1 + 7K] across ranks (N > 1) -> chain rule to particle space -> SVGD/AMSGrad update.
+backward kernels over all B x S (particle, chunk) sequences -> sum over chunks (HIP) -> ONE all-reduce of
+[B + 1, 1 + 7K] across ranks (N > 1) -> prior + chain rule to particle space (HIP) -> SVGD/AMSGrad update (HIP).
 Work per step = B * S * L scored site.particles per GPU (the W warm-up sites of every chunk are
 run but not counted).  Before the W warm-up steps there is an untimed set-up: data generation, upload, and ONE step whose
 result is discarded, in which the library selects (tunes) its plan for the launch shape and torch's allocator gets its
@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--autograd-step", action="store_true", help="chain rule by torch autograd instead of the fused HIP tail (dev A/B)")
     ap.add_argument("--variant", default="", help="R:T override for the kernel variant (dev)")
     ap.add_argument("--nrm", type=int, default=0, help="rescale interval override (dev; 0 = library default)")
     a = ap.parse_args()
@@ -379,7 +380,18 @@ def main():
     c1 = 1.0  # full pass: every one of the N_total chunks once -> weight N/S = 1 (mcmc.py:244)
     flags = torch.zeros(2, dtype=torch.float64, device=dev)  # kernel flags of all steps, summed on the device
 
+    from phlash_amd import step as fused_step
+
+    use_fused = not a.autograd_step and fused_step.fusable(template, kern)
+
     def one_step(state):
+        if use_fused:
+            # what fit() runs: parameter map -> kernels -> chunk sums + flags -> (all-reduce) -> prior + chain rule,
+            # a fixed sequence of HIP launches (phlash_amd/step.py), then the SVGD update
+            _, g = fused_step.log_density_and_grad(template, state.particles, (1.0, c1, 1.0), kern, inds, afs)
+            flags.add_(kern._flags)
+            return svgd.step(state, g, lr=0.1)
+        # the same step through autograd (the definition the fused path is tested against; --autograd-step)
         xs = state.particles.detach().requires_grad_(True)
         mcp = template.from_flat(xs)
         pp = particles_to_psmc(template, xs)  # HIP: particle -> PSMCParams (+ Jacobian), one launch

@@ -90,6 +90,29 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
 int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x,
                   int64_t B, double* params, double* jac, void* stream);
 
+/* The same, and the [B, 7, K] block once more rounded to float32 (params_f32, may be NULL): what a float32 kernel
+ * object takes in phk_loglik, without a conversion launch in between. */
+int phk_param_map_rounded(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x,
+                      int64_t B, double* params, double* jac, float* params_f32, void* stream);
+
+/* The tail of a sampler step between the likelihood kernels and the SVGD update, two launches.
+ * phk_reduce_chunks: the sum over the minibatch that model.py:57 takes (``.sum()``), for value and gradient, and the
+ *   hand-over of the kernel object's flags, in the layout that is all-reduced over the ranks:
+ *     ll   device double [B, S], grad device [B, S, 7, K] (float or double as the handle): outputs of phk_loglik
+ *     buf  device double [B + 1, 1 + 7K]: row b = [sum_s ll, sum_s grad]; row B = [underflow flag, bad-index flag,
+ *          0...] as 0.0 / 1.0 (the handle's flag word is cleared, as by phk_take_flags_async)
+ * phk_chain_rule: log density of every particle and its gradient in particle space -- what the reference obtains
+ *   with jax.grad through log_density (src/phlash/model.py:24-73) and PSMCParams.from_dm(MCMCParams.to_dm()):
+ *     logp[b] = c_prior * log_prior(x_b) + c_hmm * buf[b, 0] + c_extra * extra_val[b]
+ *     grad[b] = c_prior * d log_prior / d x_b + c_hmm * jac[b]^T buf[b, 1:] + c_extra * extra_grad[b]
+ *   x [B, P+3], jac [B, 7K, P+3] (phk_param_map), buf as above after the all-reduce; extra_val [B] / extra_grad
+ *   [B, P+3] may be NULL (the AFS term, evaluated elsewhere).  A particle whose logp is not finite gets -inf and a
+ *   zero gradient (model.py:73 under jax.grad). */
+int phk_reduce_chunks(phk_handle* h, const double* ll, const void* grad, int64_t B, int64_t S, double* buf, void* stream);
+int phk_chain_rule(int device, int K, int P, double alpha, double beta, const double* x, const double* buf,
+                   const double* jac, int64_t B, double c_prior, double c_hmm, const double* extra_val,
+                   const double* extra_grad, double c_extra, double* logp, double* grad, void* stream);
+
 /* log_prior of the whole population with its gradient, one launch.  Replaces log_prior
  * (src/phlash/model.py:11-21) under vmap + jax.grad:
  *   value[b] = logN(log(rho/theta); 0, 1) - alpha * sum_i (log c_{i+1} - log c_i)^2 - beta * |x_b|^2
@@ -106,10 +129,11 @@ int phk_log_prior(int device, int P, double alpha, double beta, const double* x,
  * Replaces what the reference delegates to blackjax.svgd(..., optax.amsgrad(lr)) per iteration
  * (src/phlash/mcmc.py:178-199, 279; blackjax 1.2.5 / optax 0.2.6).  All arrays device float64:
  *   x, grad_logp, mu, nu, nu_max, x_out [B, D] (mu, nu, nu_max updated in place; x_out must not alias x);
- *   h_in, h_out scalars (may alias); dist_ws workspace of B (B - 1) / 2 doubles, on return the pairwise
- *   distances of x_out (strict lower triangle).  h_out = NULL skips the median (one workgroup selects it:
- *   meant for up to a couple of hundred particles; beyond that take the median of dist_ws with a device-wide
- *   sort).  B <= 4096, D <= 72. */
+ *   h_in, h_out scalars (may alias); dist_ws workspace of phk_svgd_workspace_doubles(B) doubles, whose first
+ *   B (B - 1) / 2 hold the pairwise distances of x_out on return (strict lower triangle).  The median is an exact
+ *   bucket select: by one workgroup up to 256 particles, over the whole chip beyond (the reference's default is
+ *   500).  h_out = NULL skips it.  B <= 4096, D <= 72. */
+int64_t phk_svgd_workspace_doubles(int64_t B);
 int phk_svgd_step(int device, int64_t B, int D, const double* x, const double* grad_logp, double* mu, double* nu,
                   double* nu_max, const double* h_in, double* h_out, double* x_out, double* dist_ws, int64_t count,
                   double lr, double b1, double b2, double eps, void* stream);

@@ -21,9 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace phk {
+#include "step_args.h"
 
-constexpr int PM_MAXK = 64;
+namespace phk {
 
 struct Dual {
     double v, d;
@@ -109,16 +109,6 @@ __device__ __forceinline__ Row3 step_expQ(Row3 row, Dual r, Dual c) {
     return o;
 }
 
-struct PMArgs {
-    int K, P, D;
-    double theta;
-    int8_t epoch[PM_MAXK];  // epoch index of every hidden state (pattern expansion, util.py:35-37)
-    const double* x;        // [B, D]
-    double* params;         // [B, 7, K]
-    double* jac;            // [B, 7K, D] or null
-    int64_t B;
-};
-
 // One pass over the hidden states with O(1) state per thread: round 1's version kept t, c, ect, the transition
 // factors and the survival differences in per-thread arrays of dual numbers indexed by a run-time k (9 KB of
 // scratch per thread), and spent most of its 130 us per launch on scratch traffic.  Same operations in the
@@ -133,7 +123,10 @@ __global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
     double* out = A.params + bidx * 7 * K;
     double* jac = A.jac ? A.jac + bidx * 7 * K * D : nullptr;
     auto put = [&](int row, int k, Dual val) {
-        if (j == 0) out[row * K + k] = val.v;
+        if (j == 0) {
+            out[row * K + k] = val.v;
+            if (A.params_f32) A.params_f32[bidx * 7 * K + row * K + k] = (float)val.v;
+        }
         if (jac && j < D) jac[(size_t)(row * K + k) * D + j] = val.d;
     };
 
@@ -241,13 +234,8 @@ __global__ __launch_bounds__(128) void param_map_kernel(PMArgs A) {
 // log_prior of a whole population with its gradient (model.py:11-21): one thread per particle.
 //   value = logN(log(rho/theta); 0, 1) - alpha sum_i (log c_{i+1} - log c_i)^2 - beta |x|^2,
 //   rho/theta = 0.1 + 9.9 sigmoid(x[P+2]) (params.py:110-112), c = softplus(x[2 .. 2+P)) per epoch.
-__global__ void log_prior_kernel(int P, double alpha, double beta, const double* __restrict__ X, int64_t B,
-                                 double* __restrict__ value, double* __restrict__ grad) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__device__ double log_prior_one(int P, double alpha, double beta, const double* __restrict__ x, double* __restrict__ g) {
     const int D = P + 3;
-    const double* x = X + b * D;
-    double* g = grad ? grad + b * D : nullptr;
     double xx = 0.0;
     for (int i = 0; i < D; ++i) xx += x[i] * x[i];
     const double r = x[P + 2];
@@ -283,7 +271,116 @@ __global__ void log_prior_kernel(int P, double alpha, double beta, const double*
         g[1] = -2.0 * beta * x[1];
         g[P + 2] = -z * 9.9 * sg * (1.0 - sg) / rot - 2.0 * beta * r;
     }
-    value[b] = ret - alpha * rough - beta * xx;
+    return ret - alpha * rough - beta * xx;
+}
+
+__global__ void log_prior_kernel(int P, double alpha, double beta, const double* __restrict__ X, int64_t B,
+                                 double* __restrict__ value, double* __restrict__ grad) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int D = P + 3;
+    value[b] = log_prior_one(P, alpha, beta, X + b * D, grad ? grad + b * D : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tail of a sampler step between the likelihood kernels and the SVGD update, in two launches (it was ~25 torch
+// launches of 5-20 us: sums over the chunk axis, buffer assembly, the flag hand-over, prior, the autograd chain):
+//   reduce_chunks : ll [B, S] f64 and d ll / d params [B, S, J = 7K] (float or double)  ->  buf [B + 1, 1 + J] f64,
+//                   row b = [sum_s ll, sum_s grad], row B = the kernel object's flags (underflow, bad index; the
+//                   device word is cleared) -- the buffer that is all-reduced over the ranks (parallel.py);
+//   chain_rule    : buf (reduced), the Jacobian d params / d x [B, J, D] of phk_param_map and the particles x
+//                   [B, D]  ->  logp [B] = c_prior log_prior(x) + c_hmm sum ll (+ c_extra extra_val) and its gradient
+//                   [B, D] = c_prior d log_prior + c_hmm J^T sum grad (+ c_extra extra_grad); a particle whose
+//                   logp is not finite gets -inf and a zero gradient (model.py:73 under jax.grad).
+// Every sum has a fixed order (bit-reproducible).
+// ---------------------------------------------------------------------------------------------
+constexpr int RC_NT = 1024;
+
+template <typename real>
+__global__ __launch_bounds__(RC_NT) void reduce_chunks_kernel(const double* __restrict__ ll, const real* __restrict__ g,
+                                                              int64_t B, int64_t S, int J, double* __restrict__ buf,
+                                                              int* flags) {
+    __shared__ double red[RC_NT];
+    __shared__ int fw;
+    const int64_t b = blockIdx.x;
+    const int t = threadIdx.x;
+    double* row = buf + b * (1 + J);
+    if (b == B) {  // the flag row
+        if (t == 0) fw = flags ? atomicExch(flags, 0) : 0;
+        __syncthreads();
+        const int w = fw;
+        for (int i = t; i < 1 + J; i += RC_NT) row[i] = i == 0 ? ((w & 1) ? 1.0 : 0.0) : (i == 1 ? ((w & 2) ? 1.0 : 0.0) : 0.0);
+        return;
+    }
+    // gradient: lane j of part p adds chunks p, p + parts, ...; the parts are then added in part order
+    const int parts = RC_NT / J;
+    const int part = t / J, j = t - part * J;
+    double acc = 0.0;
+    if (part < parts) {
+        const real* src = g + (b * S) * (int64_t)J + j;
+        for (int64_t s = part; s < S; s += parts) acc += (double)src[s * J];
+        red[t] = acc;
+    }
+    __syncthreads();
+    if (t < J) {
+        double tot = 0.0;
+        for (int p = 0; p < parts; ++p) tot += red[p * J + t];
+        row[1 + t] = tot;
+    }
+    __syncthreads();
+    // log-likelihood: strided partial sums, then a fixed tree
+    double l = 0.0;
+    for (int64_t s = t; s < S; s += RC_NT) l += ll[b * S + s];
+    red[t] = l;
+    __syncthreads();
+    for (int off = RC_NT / 2; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    if (t == 0) row[0] = red[0];
+}
+
+hipError_t launch_reduce_chunks(const double* ll, const void* g, bool g_f64, int64_t B, int64_t S, int J, double* buf, int* flags,
+                                hipStream_t st) {
+    if (g_f64)
+        hipLaunchKernelGGL(reduce_chunks_kernel<double>, dim3((unsigned)(B + 1)), dim3(RC_NT), 0, st, ll, (const double*)g, B, S, J, buf, flags);
+    else
+        hipLaunchKernelGGL(reduce_chunks_kernel<float>, dim3((unsigned)(B + 1)), dim3(RC_NT), 0, st, ll, (const float*)g, B, S, J, buf, flags);
+    return hipGetLastError();
+}
+
+constexpr int CR_MAXJ = 7 * PM_MAXK, CR_MAXD = PM_MAXK + 3;
+
+__global__ __launch_bounds__(128) void chain_rule_kernel(CRArgs A) {
+    __shared__ double G[CR_MAXJ];
+    __shared__ double pg[CR_MAXD];
+    __shared__ double pv;
+    const int64_t b = blockIdx.x;
+    const int t = threadIdx.x, J = A.J, D = A.D;
+    const double* row = A.buf + b * (1 + J);
+    for (int j = t; j < J; j += 128) G[j] = row[1 + j];
+    if (t == 127) pv = log_prior_one(A.P, A.alpha, A.beta, A.x + b * D, pg);  // (a lane that holds no coordinate)
+    __syncthreads();
+    double acc = 0.0;
+    if (t < D) {
+        const double* jc = A.jac + b * (int64_t)J * D + t;
+        for (int j = 0; j < J; ++j) acc = fma(G[j], jc[(int64_t)j * D], acc);
+    }
+    double lp = A.c_prior * pv + A.c_hmm * row[0];
+    if (A.extra_val) lp += A.c_extra * A.extra_val[b];
+    const bool fin = isfinite(lp);
+    if (t < D) {
+        double gx = A.c_prior * pg[t] + A.c_hmm * acc;
+        if (A.extra_grad) gx += A.c_extra * A.extra_grad[b * D + t];
+        A.grad[b * D + t] = fin ? gx : 0.0;
+    }
+    if (t == 0) A.logp[b] = fin ? lp : -INFINITY;
+}
+
+hipError_t launch_chain_rule(const CRArgs& a, int64_t B, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(chain_rule_kernel, dim3((unsigned)B), dim3(128), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,

@@ -17,6 +17,7 @@
 #include "../../include/phlash_hip.h"
 #define PHK_WITH_PACK 1
 #include "psmc_kernels.hip"
+#include "step_args.h"
 
 namespace phk {
 #define PHK_DECL(tag)                                                                                                  \
@@ -29,35 +30,6 @@ PHK_DECL(f32_4) PHK_DECL(f32_8) PHK_DECL(f32_16) PHK_DECL(f32_32) PHK_DECL(f32_6
 PHK_DECL(f64_4) PHK_DECL(f64_8) PHK_DECL(f64_16) PHK_DECL(f64_32) PHK_DECL(f64_64)
 #undef PHK_DECL
 
-constexpr int PM_MAXK = 64;
-struct PMArgs {  // must match param_map.hip
-    int K, P, D;
-    double theta;
-    int8_t epoch[PM_MAXK];
-    const double* x;
-    double* params;
-    double* jac;
-    int64_t B;
-};
-hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
-hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
-                            hipStream_t st);
-
-constexpr int SV_MAXD = 72, SV_MAXB = 4096;
-struct SVArgs {  // must match svgd_step.hip
-    int64_t B;
-    int D;
-    const double* x;
-    const double* g;
-    double* mu;
-    double* nu;
-    double* nu_max;
-    const double* h_in;
-    double* x_out;
-    double den1, den2;
-    double lr, b1, b2, eps;
-};
-hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hipStream_t st);
 }  // namespace phk
 
 namespace {
@@ -136,7 +108,7 @@ struct phk_handle {
     int K = 0, device = 0, dbl = 0;
     int64_t N = 0, L = 0, Lw = 0;
     uint32_t* packed = nullptr;
-    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, part, tune_ll, tune_grad, risk;
+    DevBuf ckpt, aux, gacc, eblk, eseg, bseg, fseg, bpi, part, tune_ll, tune_grad, risk, ops;
     int64_t ws_limit = 0;
     int force_R = 0, force_T = 0, nrm = DEFAULT_NRM;
     int mode = -1;     // -1 auto, 0 serial, 1 segmented
@@ -332,6 +304,26 @@ Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
     return p;
 }
 
+// The one-state-per-lane kernels (K = 16, float32, rescale interval 4) take their dense hom-run operators from a table
+// built once per launch sequence, one [2 forms][9 powers][16][16] block per parameter block of the launch (18 KB:
+// one per particle when the chunks share it, one per (particle, chunk) otherwise).
+bool dense_capable(const phk_handle* h) { return h->K == 16 && !h->dbl && h->nrm == 4; }
+bool plan_uses_dense(const phk_handle* h, const Plan& p) { return dense_capable(h) && (p.R == 16 || p.R1 == 16 || p.R2 == 16); }
+int64_t param_blocks(const phk::KArgs& a) { return a.B * (a.pstride_s != 0 ? a.S : 1); }
+int build_dense_ops(phk_handle* h, phk::KArgs* a, hipStream_t st) {
+    const int64_t nblk = param_blocks(*a);
+    if (int rc = h->ops.ensure((size_t)nblk * 2 * phk::DENSE_OPS_FLOATS * sizeof(float)); rc != PHK_OK) return rc;
+    float* f = (float*)h->ops.p;
+    float* b = f + nblk * phk::DENSE_OPS_FLOATS;
+    hipLaunchKernelGGL(phk::dense_ops_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)a->params, a->pstride_b, a->pstride_s,
+                       a->pstride_s != 0 ? a->S : (int64_t)1, f, b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PHK_EHIP, "dense operator table launch: %s", hipGetErrorString(e));
+    a->ops_f = f;
+    a->ops_b = b;
+    return PHK_OK;
+}
+
 // scratch shared by both plans, sized for one launch of `nseq` sequences
 int ensure_scratch(phk_handle* h, int64_t nseq) {
     const int K = h->K;
@@ -451,6 +443,7 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
     phk::KArgs a = proto;
     a.ll = (double*)h->tune_ll.p;
     a.grad = want_grad ? h->tune_grad.p : nullptr;
+    if (dense_capable(h) && (rc = build_dense_ops(h, &a, st)) != PHK_OK) return rc;
     auto timed = [&](const phk::KArgs& ka, const Plan& p, bool grad, float* ms) -> int {
         for (int rep = 0; rep < 2; ++rep) {  // rep 0 loads the code objects / warms the caches
             HIP_TRY(hipEventRecord(e0, st));
@@ -752,7 +745,7 @@ int phk_destroy(phk_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fwd) (void)hipEventDestroy(h->ev_fwd);
     if (h->side) (void)hipStreamDestroy(h->side);
-    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->part, &h->tune_ll, &h->tune_grad, &h->risk})
+    for (DevBuf* b : {&h->ckpt, &h->aux, &h->gacc, &h->eblk, &h->eseg, &h->bseg, &h->fseg, &h->bpi, &h->part, &h->tune_ll, &h->tune_grad, &h->risk, &h->ops})
         b->release();
     if (h->packed) (void)hipFree(h->packed);
     delete h;
@@ -908,6 +901,14 @@ int phk_debug_copy_ckpt(phk_handle* h, void* host, int64_t bytes) {
     HIP_TRY(hipMemcpy(host, h->ckpt.p, (size_t)std::min<int64_t>(bytes, (int64_t)h->ckpt.cap), hipMemcpyDeviceToHost));
     return PHK_OK;
 }
+// ... and the beta scan's segment seeds [nseg + 1, nseq, K] reals with their exponents [nseg + 1, nseq] int32
+int phk_debug_copy_seeds(phk_handle* h, void* bseg_host, int64_t bseg_bytes, void* fseg_host, int64_t fseg_bytes) {
+    if (!h || !bseg_host || !fseg_host) return fail(PHK_EINVAL, "NULL argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bseg_host, h->bseg.p, (size_t)std::min<int64_t>(bseg_bytes, (int64_t)h->bseg.cap), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fseg_host, h->fseg.p, (size_t)std::min<int64_t>(fseg_bytes, (int64_t)h->fseg.cap), hipMemcpyDeviceToHost));
+    return PHK_OK;
+}
 #endif
 
 int64_t phk_workspace_bytes(phk_handle* h) {
@@ -960,6 +961,11 @@ int phk_timing_totals(phk_handle* h, double* fwd_ms, double* bwd_ms, int* n_laun
 
 int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x, int64_t B,
                   double* params, double* jac, void* stream) {
+    return phk_param_map_rounded(device, K, P, epoch_of_state, theta, x, B, params, jac, nullptr, stream);
+}
+
+int phk_param_map_rounded(int device, int K, int P, const int32_t* epoch_of_state, double theta, const double* x, int64_t B,
+                          double* params, double* jac, float* params_f32, void* stream) {
     if (K < 3 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [3, %d]", K, phk::PM_MAXK);
     if (P < 1 || P > K) return fail(PHK_EINVAL, "P=%d epochs for K=%d states", P, K);
     if (!epoch_of_state || !x || !params) return fail(PHK_EINVAL, "NULL argument");
@@ -977,6 +983,7 @@ int phk_param_map(int device, int K, int P, const int32_t* epoch_of_state, doubl
     a.params = params;
     a.jac = jac;
     a.B = B;
+    a.params_f32 = params_f32;
     HIP_TRY(hipSetDevice(device));
     hipError_t e = phk::launch_param_map(a, (hipStream_t)stream);
     if (e != hipSuccess) return fail(PHK_EHIP, "param_map kernel launch: %s", hipGetErrorString(e));
@@ -993,6 +1000,47 @@ int phk_log_prior(int device, int P, double alpha, double beta, const double* x,
     if (e != hipSuccess) return fail(PHK_EHIP, "log_prior kernel launch: %s", hipGetErrorString(e));
     return PHK_OK;
 }
+
+int phk_reduce_chunks(phk_handle* h, const double* ll, const void* grad, int64_t B, int64_t S, double* buf, void* stream) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (!ll || !grad || !buf) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0 || S < 0) return fail(PHK_EINVAL, "B and S must be >= 0");
+    HIP_TRY(hipSetDevice(h->device));
+    hipError_t e = phk::launch_reduce_chunks(ll, grad, h->dbl != 0, B, S, 7 * h->K, buf, (int*)h->risk.p, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "reduce_chunks kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+int phk_chain_rule(int device, int K, int P, double alpha, double beta, const double* x, const double* buf, const double* jac,
+                   int64_t B, double c_prior, double c_hmm, const double* extra_val, const double* extra_grad, double c_extra,
+                   double* logp, double* grad, void* stream) {
+    if (K < 3 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [3, %d]", K, phk::PM_MAXK);
+    if (P < 1 || P > K) return fail(PHK_EINVAL, "P=%d epochs for K=%d states", P, K);
+    if (!x || !buf || !jac || !logp || !grad) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0) return fail(PHK_EINVAL, "B must be >= 0");
+    phk::CRArgs a;
+    a.J = 7 * K;
+    a.D = P + 3;
+    a.P = P;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.c_prior = c_prior;
+    a.c_hmm = c_hmm;
+    a.c_extra = c_extra;
+    a.x = x;
+    a.buf = buf;
+    a.jac = jac;
+    a.extra_val = extra_val;
+    a.extra_grad = extra_grad;
+    a.logp = logp;
+    a.grad = grad;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_chain_rule(a, B, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "chain_rule kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+int64_t phk_svgd_workspace_doubles(int64_t B) { return B > 0 ? phk::svgd_ws_doubles(B) : 1; }
 
 int phk_svgd_step(int device, int64_t B, int D, const double* x, const double* grad_logp, double* mu, double* nu,
                   double* nu_max, const double* h_in, double* h_out, double* x_out, double* dist_ws, int64_t count,
@@ -1089,6 +1137,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.seq_begin = a.seq_end = 0;
         a.N = h->N;
         a.part = h->part.p;
+        a.ops_f = a.ops_b = nullptr;  // build_dense_ops sets them where the plan runs a one-state-per-lane kernel
         return a;
     };
 
@@ -1114,7 +1163,10 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         const int64_t nb = std::min(Bs, B - b0);
         for (int64_t s0 = 0; s0 < S; s0 += Ss) {
             const int64_t ns = std::min(Ss, S - s0);
-            const phk::KArgs a = make_args(b0, nb, s0, ns);
+            phk::KArgs a = make_args(b0, nb, s0, ns);
+            if (plan_uses_dense(h, plan)) {
+                if (int rc = build_dense_ops(h, &a, st); rc != PHK_OK) return rc;
+            }
             if (h->poison) {
                 // diagnostic (environment PHK_POISON=<byte>, e.g. 255 = NaN patterns): fill every scratch buffer with that byte before every
                 // launch sequence, so that a kernel reading what no kernel of this launch sequence wrote shows up as

@@ -236,11 +236,27 @@ __device__ __forceinline__ float dense16(float x, const float (&d)[16]) {
     return (c0 + c1) + (c2 + c3);
 }
 
+// Round 4: runs that END in a het or a missing site are dense steps too.  A diag(emis1) = M_h diag(emis1 / emis0) and
+// A = M_h diag(1 / emis0), so "n - 1 hom sites, then a het" is M_h^n followed by ONE multiply by a per-state ratio
+// (forward form; the beta scan multiplies first).  With every power M_h^1 .. M_h^8 in registers (128 VGPRs; these
+// kernels are compiled for two waves per SIMD = 256) a run of any length up to 8 is one dense step, chosen by a
+// wave-uniform switch on the run length: the four sequences of a wave read the SAME observation row by construction
+// (see the particle-major mapping in fwd_kernel), so the codes are scalars.  Before, a het cost two structured steps
+// (~35 instructions each for a lone wave), a broken hom run and two rescales: the reference's production shape lost
+// 26 % (5 % hets) to 55 % (10 %) of its rate against 1 %-het rows (profiles/r03_ab_experiments.txt item 18).
+#ifndef PHK_DENSE_UNI
+#define PHK_DENSE_UNI 1  // A/B: 0 = waves with one observation row take the wave-vote path like any other
+#endif
+#ifndef PHK_DENSE_UNI_SCAN
+#define PHK_DENSE_UNI_SCAN PHK_DENSE_UNI  // ... the beta scan alone
+#endif
 template <bool ON>
 struct DenseOps {};
 template <>
 struct DenseOps<true> {
-    float D2[16], D4[16], D8[16], D16[16];  // M_h^2, ^4, ^8, ^16: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
+    float P[8][16];  // P[n-1] = M_h^n, n = 1..8: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
+    float D16[16];   // M_h^16
+    float rhet, rmis;  // this lane's state: emis1 / emis0 and 1 / emis0
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -489,71 +505,76 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
 
     // sum over the K states of the sequence (all lanes of the group get the same bits)
     __device__ __forceinline__ real total(const V (&x)[NP]) const {
+        // One state per lane: the pair's second half is padding.  It stays exactly 0 in the forward recursion, but
+        // the adjoint recursion (beta_prev) leaves pre(b.*w) + carry in it -- recomputed by every structured step and
+        // read by none, so harmless there; the dense steps do not touch it, and a stale value from the last
+        // structured step would take over the normaliser once the real state has decayed (found in round 4, when
+        // het sites became dense steps: the scan stopped rescaling and beta underflowed).
+        if constexpr (SPL == 1) return g.sum(x[0][0]);
         V acc = x[0];
 #pragma unroll
         for (int h = 1; h < NP; ++h) acc = acc + x[h];
         return g.sum(acc[0] + acc[1]);
     }
 
-    // dense hom operators, forward (row-vector) form: slot j of lane i = (M_h^n)[j][i],
-    // M_h[j][i] = A[j][i] emis0[i],  A[j][i] = b[i] (j > i), d[i] (j == i), u[j] v[i] (j < i).
-    // Built in float64 and rounded once: the same operator is applied L/4 times, so an error in
-    // it acts like a perturbation of the parameters (coherent over the sequence), not like round-off.
-    __device__ __forceinline__ void build_dense_fwd(int rank) {
+    // The dense hom operators of this lane's sequence, from the table dense_ops_kernel built for the launch (see there):
+    // slot j of lane i = (M_h^n)[j][i] in the forward (row-vector) form, (M_h^n)[i][j] in the beta-scan (column-vector)
+    // form; the table holds lane i's 16 slots of a power contiguously in either form.  Rounds 1-3 built the powers in
+    // the prologue of every wave (float64 products over DPP broadcasts: ~5,000 instructions, 1.4 KB of scratch per
+    // lane); with all eight powers that prologue outgrew the 2,048-site problem the tuner times these kernels on.
+    template <bool NEED16>
+    __device__ __forceinline__ void load_dense(const float* __restrict__ ops, int rank) {
         if constexpr (has_dense<real, K, R>()) {
-            double M[16];
-            build_row<0>(M, rank, (double)b[0][0], (double)d[0][0], (double)u[0][0], (double)v[0][0], (double)etab[0]);
-            finish_dense(M);
-        }
-    }
-    // ... beta-scan (column-vector) form: slot j of lane i = (M_h^n)[i][j],
-    // M_h[i][j] = A[i][j] emis0[j],  A[i][j] = b[j] (i > j), d[j] (i == j), u[i] v[j] (i < j)
-    __device__ __forceinline__ void build_dense_bwd(int rank) {
-        if constexpr (has_dense<real, K, R>()) {
-            double M[16];
-            build_col<0>(M, rank, (double)b[0][0], (double)d[0][0], (double)u[0][0], (double)v[0][0], (double)etab[0]);
-            finish_dense(M);
-        }
-    }
-    template <int J>
-    static __device__ __forceinline__ void build_row(double (&M)[16], int rank, double bi, double di, double ui, double vi, double e0) {
-        if constexpr (J < 16) {
-            const double uj = dpp_<0x150 + J>(ui);  // row_share: lane J of this row
-            M[J] = (J > rank ? bi : (J == rank ? di : uj * vi)) * e0;
-            build_row<J + 1>(M, rank, bi, di, ui, vi, e0);
-        }
-    }
-    template <int J>
-    static __device__ __forceinline__ void build_col(double (&M)[16], int rank, double bi, double di, double ui, double vi, double e0) {
-        if constexpr (J < 16) {
-            const double bj = dpp_<0x150 + J>(bi), dj = dpp_<0x150 + J>(di), vj = dpp_<0x150 + J>(vi), ej = dpp_<0x150 + J>(e0);
-            M[J] = (rank > J ? bj : (rank == J ? dj : ui * vj)) * ej;
-            build_col<J + 1>(M, rank, bi, di, ui, vi, e0);
-        }
-    }
-    template <int J>
-    static __device__ __forceinline__ double dot_share(double x, const double (&m)[16]) {
-        if constexpr (J == 16) return 0.0;
-        else return __builtin_fma(dpp_<0x150 + J>(x), m[J], dot_share<J + 1>(x, m));
-    }
-    // D2 = M M, D4 = D2 D2, D8 = D4 D4, D16 = D8 D8 (both forms: slot j of a product is the dense step applied to slot j of
-    // the left factor read as a vector spread over the lanes of the row)
-    __device__ __forceinline__ void finish_dense(const double (&M)[16]) {
-        if constexpr (has_dense<real, K, R>()) {
-            double P2[16], P4[16], P8[16];
+            const float4* src = (const float4*)(ops + rank * 16);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) P2[j] = dot_share<0>(M[j], M);
+            for (int n = 0; n < 8; ++n) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) P4[j] = dot_share<0>(P2[j], P2);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) P8[j] = dot_share<0>(P4[j], P4);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                this->D2[j] = (float)P2[j];
-                this->D4[j] = (float)P4[j];
-                this->D8[j] = (float)P8[j];
-                this->D16[j] = (float)dot_share<0>(P8[j], P8);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v4 = src[n * 64 + q];
+                    this->P[n][4 * q + 0] = v4.x;
+                    this->P[n][4 * q + 1] = v4.y;
+                    this->P[n][4 * q + 2] = v4.z;
+                    this->P[n][4 * q + 3] = v4.w;
+                }
             }
+            if constexpr (NEED16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v4 = src[8 * 64 + q];
+                    this->D16[4 * q + 0] = v4.x;
+                    this->D16[4 * q + 1] = v4.y;
+                    this->D16[4 * q + 2] = v4.z;
+                    this->D16[4 * q + 3] = v4.w;
+                }
+            }
+            const double e0 = (double)etab[0], e1 = (double)etab[EROW];
+            this->rhet = (float)(e1 / e0);
+            this->rmis = (float)(1.0 / e0);
+            // (pinned: left alone the compiler sinks the divisions into the site loop to save two registers)
+            asm volatile("" : "+v"(this->rhet), "+v"(this->rmis));
+        }
+    }
+    // x <- x M_h^n (forward form) / M_h^n x (beta-scan form) for a wave-uniform n in [1, NMAX], NMAX = 8 or 16: one
+    // dense step for n <= 8 and n = 16, two for 9..15
+    template <int NMAX>
+    __device__ __forceinline__ float hom_power(float x, int n) const {
+        if constexpr (has_dense<real, K, R>()) {
+            if constexpr (NMAX > 8) {
+                if (n == 16) return dense16(x, this->D16);
+                if (n > 8) {
+                    x = dense16(x, this->P[7]);
+                    n -= 8;
+                }
+            }
+            if (n == 8) return dense16(x, this->P[7]);
+            if (n & 4) {
+                if (n & 2) return (n & 1) ? dense16(x, this->P[6]) : dense16(x, this->P[5]);
+                return (n & 1) ? dense16(x, this->P[4]) : dense16(x, this->P[3]);
+            }
+            if (n & 2) return (n & 1) ? dense16(x, this->P[2]) : dense16(x, this->P[1]);
+            return dense16(x, this->P[0]);
+        } else {
+            return x;
         }
     }
 
@@ -691,7 +712,13 @@ struct KArgs {
     // part[((y - 1) * (seq_hi - seq_begin) + (seq - seq_begin)) * 6 * K ...] (real); unit 0 adds into
     // gacc (it alone touches the sequence's row there); grad_finalize_kernel adds them up in unit order.
     void* part;
+    // dense hom-run operators of the one-state-per-lane kernels (K = 16, float32; dense_ops_kernel): per parameter block
+    // [9 powers M_h^1..8, M_h^16][lane 16][slot 16] floats, forward form and beta-scan form; null where those kernels are not used
+    const float* ops_f;
+    const float* ops_b;
 };
+constexpr int DENSE_NPOW = 9;
+constexpr int DENSE_OPS_FLOATS = DENSE_NPOW * 256;  // per parameter block and form
 
 // bits of the sticky device flag word (KArgs::risk)
 constexpr int FLAG_UNDERFLOW = 1;  // a rescale found the mass below 2^RISK_EXP (see below)
@@ -818,12 +845,21 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.build_dense_fwd(rank);
+    if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank);
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
+    // Do the four sequences of this wave read ONE observation row (true for every wave of a range of whole particles
+    // whose particle count is a multiple of four, e.g. the reference's 500), and are their hom emissions far enough
+    // from zero for the het / missing ratios to exist?  Then the codes are scalars and every run of sites is one
+    // dense step (uni_block below).  Other waves keep the wave-vote path.
+    bool uni = false;
+    if constexpr (DENSE && PHK_DENSE_UNI != 0) {
+        const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
+        uni = __all((int)ss == ss0 && lane.etab[0] > 0x1p-30f) != 0;
+    }
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
-    int hom_run = 0;  // dense kernels: hom sites stepped over since the last rescale
+    int hom_run = 0;  // dense kernels: rescale debt -- hom sites stepped over since the last rescale (uniform path: + 16 per het / missing site)
     int eb_min = 0;   // smallest exponent total of any checkpoint block
     double llW = 0.0;
     // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
@@ -895,7 +931,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 #pragma unroll
             for (int h8 = 0; h8 < T / 8; ++h8) {
                 if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
-                    a[0][0] = dense16(a[0][0], lane.D8);
+                    a[0][0] = dense16(a[0][0], lane.P[7]);
                     hom_run += 8;
                     if (hom_run >= PHK_DENSE_RESCALE_SITES) {
                         hom_run = 0;
@@ -910,13 +946,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
                     const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
                     if (__all(c4 == 0u)) {
-                        a[0][0] = dense16(a[0][0], lane.D4);
+                        a[0][0] = dense16(a[0][0], lane.P[3]);
                     } else {
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh) {
                             const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
                             if (__all(c2 == 0u)) {
-                                a[0][0] = dense16(a[0][0], lane.D2);
+                                a[0][0] = dense16(a[0][0], lane.P[1]);
                             } else {
                                 real sc;
                                 V e[NP];
@@ -933,6 +969,49 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 }
             }
         }
+    };
+    // One full block of a wave whose sequences share their observation row (uni): `rem` holds the block's codes as a
+    // SCALAR.  The block is cut into runs "hom^(n-1), then a het or missing site" (the last run may have no such end);
+    // a run is one dense M_h^n step plus, for its end, one multiply by emis1 / emis0 or 1 / emis0.  At 5 % hets + 1 %
+    // missing a mixed block is ~2 dense steps where it used to be one or two dense steps, two structured sites and two
+    // rescales.  Rescales: when the debt (1 per hom site, 16 per het / missing site) reaches PHK_DENSE_RESCALE_SITES,
+    // i.e. after at most 64 hom or 4 other sites as before.  Returns the exponent taken out of the block.
+    auto uni_block = [&](uint32_t rem) -> int {
+        int dE = 0;
+        if constexpr (DENSE) {
+            if (rem == 0u) {  // all hom: most blocks
+                a[0][0] = T == 16 ? dense16(a[0][0], lane.D16) : dense16(a[0][0], lane.P[7]);
+                hom_run += T;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    dE = lane.rescale(a);
+                    ex_min = dE < ex_min ? dE : ex_min;
+                }
+                return dE;
+            }
+            int left = T;
+#pragma nounroll
+            do {
+                const int tz = rem != 0u ? (__builtin_ctz(rem) >> 1) : 32;
+                const bool stop = tz < left;  // the run ends in a het / missing site
+                const int run = stop ? tz + 1 : left;
+                a[0][0] = lane.template hom_power<T>(a[0][0], run);
+                if (stop) {
+                    a[0][0] *= ((rem >> (2 * tz)) & 3u) == 1u ? lane.rhet : lane.rmis;
+                    hom_run += 16;
+                }
+                hom_run += run;
+                rem = run < 16 ? rem >> (2 * run) : 0u;
+                left -= run;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    const int ex = lane.rescale(a);
+                    dE += ex;
+                    ex_min = ex < ex_min ? ex : ex_min;
+                }
+            } while (left > 0);
+        }
+        return dE;
     };
     // one full block of the other layouts: a straight-line basic block of T sites (no per-site branches), the
     // emission row of the next site in flight while the current one computes
@@ -998,6 +1077,38 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
               }
               real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
               int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
+              if (DENSE && PHK_DENSE_UNI != 0 && uni) {
+                  // the piece's 64 codes as two scalar 64-bit words, shifted down one block at a time
+                  uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32);
+                  uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32);
+#pragma nounroll
+                  for (int bi = 0; bi < BPC; ++bi) {
+                      if constexpr (CKPT) {
+#if !PHK_EXP_NO_CKPT_STORE
+#pragma unroll
+                          for (int i = 0; i < SPL; ++i) ck_u[ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4)] = L::get(a, i);
+#endif
+                          ck_u += ck_step;
+                      }
+                      const int dE = uni_block((uint32_t)lo & (T == 16 ? 0xffffffffu : (1u << (2 * T)) - 1u));
+                      E += dE;
+                      if constexpr (CKPT) {
+                          eb_u[sq_off] = (int16_t)dE;
+                          eb_u += nseq;
+                          eb_min = dE < eb_min ? dE : eb_min;
+                      }
+                      lo = (lo >> (2 * T)) | (hi << (64 - 2 * T));
+                      hi >>= 2 * T;
+                  }
+                  blk += BPC;
+                  if constexpr (CKPT) {
+                      ckp += (int64_t)BPC * ck_step;
+                      ebp += (int64_t)BPC * nseq;
+                  }
+                  continue;
+              }
               uint32_t w0 = pcur.x, w1 = pcur.y, w2 = pcur.z, w3 = pcur.w;
 #pragma nounroll
               for (int bi = 0; bi < BPC; ++bi) {
@@ -1664,14 +1775,19 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.build_dense_bwd(rank);
+    if constexpr (DENSE) lane.template load_dense<true>(A.ops_b + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank);
 #pragma unroll
     for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
 #pragma unroll
     for (int i = 0; i < SPL; ++i) L::set(beta, i, real(1));
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
+    bool uni = false;  // the wave's sequences share their observation row and the emission ratios exist (see fwd_kernel)
+    if constexpr (DENSE && PHK_DENSE_UNI_SCAN != 0) {
+        const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
+        uni = __all((int)ss == ss0 && lane.etab[0] > 0x1p-30f) != 0;
+    }
     int F = 0;
-    int hom_run = 0;  // dense kernel: hom sites stepped over since the last rescale
+    int hom_run = 0;  // dense kernel: rescale debt (hom sites stepped over since the last rescale; uniform path: + 16 per het / missing site)
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
     const int nw = (int)((A.Ltot + 15) / 16);
     const int seg_words = (int)(seg_sites >> 4);  // segments are whole words (SEG_SITES = 512)
@@ -1717,7 +1833,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
 #pragma unroll
             for (int h8 = 1; h8 >= 0; --h8) {
                 if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
-                    beta[0][0] = dense16(beta[0][0], lane.D8);
+                    beta[0][0] = dense16(beta[0][0], lane.P[7]);
                     hom_run += 8;
                     if (hom_run >= PHK_DENSE_RESCALE_SITES) {
                         hom_run = 0;
@@ -1730,13 +1846,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                 for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
                     const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
                     if (__all(c4 == 0u)) {
-                        beta[0][0] = dense16(beta[0][0], lane.D4);
+                        beta[0][0] = dense16(beta[0][0], lane.P[3]);
                     } else {
 #pragma unroll
                         for (int hh = 1; hh >= 0; --hh) {
                             const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
                             if (__all(c2 == 0u)) {
-                                beta[0][0] = dense16(beta[0][0], lane.D2);
+                                beta[0][0] = dense16(beta[0][0], lane.P[1]);
                             } else {
                                 V e[NP];
                                 lane.emis(c2 >> 2, e);
@@ -1751,6 +1867,41 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
             }
         }
     };
+    // One whole word of a wave whose sequences share their observation row (see fwd_kernel, uni_block): right to left,
+    // a run is "a het or missing site (multiply by its ratio FIRST: b <- M_h (ratio .* b)), then the hom sites to its
+    // left", one dense M_h^n step; the leading run of a word may start with a hom site.
+    auto uni_word = [&](const uint32_t rem) {
+        if constexpr (DENSE) {
+            if (rem == 0u) {  // all hom
+                beta[0][0] = dense16(beta[0][0], lane.D16);
+                hom_run += 16;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    F += lane.rescale(beta);
+                }
+                return;
+            }
+            int left = 16;  // sites [0, left) are still to do; the next one is left - 1
+#pragma nounroll
+            do {
+                const uint32_t top = (rem >> (2 * (left - 1))) & 3u;
+                if (top != 0u) {
+                    beta[0][0] *= top == 1u ? lane.rhet : lane.rmis;
+                    hom_run += 16;
+                }
+                const uint32_t below = rem & ((1u << (2 * (left - 1))) - 1u);
+                const int s = below != 0u ? (31 - __builtin_clz(below)) >> 1 : -1;  // next het / missing site to the left
+                const int run = left - 1 - s;
+                beta[0][0] = lane.template hom_power<16>(beta[0][0], run);
+                hom_run += run;
+                left = s + 1;
+                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
+                    hom_run = 0;
+                    F += lane.rescale(beta);
+                }
+            } while (left > 0);
+        }
+    };
     for (; w >= 0; --pc) {
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];
@@ -1758,6 +1909,27 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
           // lean path (see fwd_kernel): a piece of four whole words, none of them the row's last (partial)
           // word: the words rotate through one register, the segment-start test is the only one left
           if (w == pc * 4 + 3 && w < nw - 1) {
+              if (DENSE && PHK_DENSE_UNI_SCAN != 0 && uni) {
+                  uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32);
+                  uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32);
+#pragma nounroll
+                  for (int k = 0; k < 4; ++k, --w) {
+                      if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
+                          real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
+#pragma unroll
+                          for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
+                          fseg_out[(int64_t)sb * nseq + seq] = F;
+                          --sb;
+                          w_store -= seg_words;
+                      }
+                      uni_word((uint32_t)(hi >> 32));
+                      hi = (hi << 32) | (lo >> 32);
+                      lo <<= 32;
+                  }
+                  continue;
+              }
               uint32_t w3 = pcur.w, w2 = pcur.z, w1 = pcur.y, w0 = pcur.x;
 #pragma nounroll
               for (int k = 0; k < 4; ++k, --w) {
@@ -1804,6 +1976,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                 }
             }
         }
+
       }
     }
 }
@@ -1850,6 +2023,57 @@ __global__ void take_flags_kernel(int* flags, double* dst) {
     const int w = atomicExch(flags, 0);
     dst[0] = (w & FLAG_UNDERFLOW) ? 1.0 : 0.0;
     dst[1] = (w & FLAG_BAD_INDEX) ? 1.0 : 0.0;
+}
+
+// Dense hom-run operators for the one-state-per-lane kernels (K = 16, float32): one workgroup per parameter block,
+// thread (r, c) owns entry [r][c].  M_h = A diag(emis0), A[r][c] = b[c] (r > c), d[c] (r == c), u[r] v[c] (r < c)
+// (hmm.py:52-65 written out as a matrix); powers 1..8 and 16 accumulated in float64 from float64 factors and rounded
+// once -- the same operator is applied thousands of times along a row, so an error in it acts like a perturbation of
+// the parameters (coherent over the sequence), not like round-off.  Both forms are written lane-major:
+//   ops_f[blk][n][i][j] = (M_h^n)[j][i]   (forward kernel: lane i holds column i)
+//   ops_b[blk][n][i][j] = (M_h^n)[i][j]   (beta scan: lane i holds row i)
+__global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict__ params, int64_t pstride_b, int64_t pstride_s,
+                                                        int64_t S_blocks, float* __restrict__ ops_f, float* __restrict__ ops_b) {
+    __shared__ double Mx[5][16][17];  // M, M^2, M^3, M^4, M^8
+    const int64_t q = blockIdx.x;
+    const int64_t bb = q / S_blocks, ss = q - bb * S_blocks;
+    const float* p = params + bb * pstride_b + ss * pstride_s;
+    const int t = threadIdx.x, r = t >> 4, c = t & 15;
+    const double bc = p[0 * 16 + c], dc = p[1 * 16 + c], ur = p[2 * 16 + r], vc = p[3 * 16 + c], e0 = p[4 * 16 + c];
+    const double m = (r > c ? bc : (r == c ? dc : ur * vc)) * e0;
+    float* of = ops_f + q * DENSE_OPS_FLOATS;
+    float* ob = ops_b + q * DENSE_OPS_FLOATS;
+    auto emit = [&](int n, double val) {
+        of[(n * 16 + c) * 16 + r] = (float)val;
+        ob[(n * 16 + r) * 16 + c] = (float)val;
+    };
+    auto mul = [&](int x, int y) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = __builtin_fma(Mx[x][r][k], Mx[y][k][c], acc);
+        return acc;
+    };
+    Mx[0][r][c] = m;
+    emit(0, m);
+    __syncthreads();
+    const double p2 = mul(0, 0);
+    Mx[1][r][c] = p2;
+    emit(1, p2);
+    __syncthreads();
+    const double p3 = mul(1, 0), p4 = mul(1, 1);
+    Mx[2][r][c] = p3;
+    Mx[3][r][c] = p4;
+    emit(2, p3);
+    emit(3, p4);
+    __syncthreads();
+    const double p5 = mul(3, 0), p6 = mul(3, 1), p7 = mul(3, 2), p8 = mul(3, 3);
+    Mx[4][r][c] = p8;
+    emit(4, p5);
+    emit(5, p6);
+    emit(6, p7);
+    emit(7, p8);
+    __syncthreads();
+    emit(8, mul(4, 4));
 }
 
 __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t L, uint32_t* __restrict__ out,

@@ -1,0 +1,61 @@
+// Argument blocks and host launchers of the kernels above the scan (param_map.hip, svgd_step.hip), shared with the
+// C ABI (phk_api.hip): one definition instead of copies that "must match".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phk {
+
+constexpr int PM_MAXK = 64;
+
+struct PMArgs {
+    int K, P, D;
+    double theta;
+    int8_t epoch[PM_MAXK];  // epoch index of every hidden state (pattern expansion, util.py:35-37)
+    const double* x;        // [B, D]
+    double* params;         // [B, 7, K]
+    double* jac;            // [B, 7K, D] or null
+    int64_t B;
+    float* params_f32;      // [B, 7, K] the same block rounded to float32 (what the float32 kernels take), or null
+};
+hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
+hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
+                            hipStream_t st);
+
+// the tail of a step (param_map.hip): chunk sums + flag hand-over, then prior + chain rule
+hipError_t launch_reduce_chunks(const double* ll, const void* g, bool g_f64, int64_t B, int64_t S, int J, double* buf, int* flags,
+                                hipStream_t st);
+struct CRArgs {
+    int J, D, P;
+    double alpha, beta, c_prior, c_hmm, c_extra;
+    const double* x;           // [B, D]
+    const double* buf;         // [>= B, 1 + J]
+    const double* jac;         // [B, J, D]
+    const double* extra_val;   // [B] or null
+    const double* extra_grad;  // [B, D] or null
+    double* logp;              // [B]
+    double* grad;              // [B, D]
+};
+hipError_t launch_chain_rule(const CRArgs& a, int64_t B, hipStream_t st);
+
+constexpr int SV_MAXD = 72;    // P + 3 <= 67
+constexpr int SV_MAXB = 4096;  // particles (the kernel row of one particle lives in LDS)
+
+struct SVArgs {
+    int64_t B;
+    int D;
+    const double* x;      // [B, D]
+    const double* g;      // [B, D] grad log p
+    double* mu;           // [B, D] in/out
+    double* nu;
+    double* nu_max;
+    const double* h_in;   // device scalar
+    double* x_out;        // [B, D]
+    double den1, den2;    // 1 - b1^count, 1 - b2^count
+    double lr, b1, b2, eps;
+};
+// dist_ws: svgd_ws_doubles(B) doubles, see phk_svgd_step in include/phlash_hip.h
+int64_t svgd_ws_doubles(int64_t B);
+hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hipStream_t st);
+
+}  // namespace phk

@@ -14,33 +14,27 @@
 //                        coordinate sums over i in index order and applies the AMSGrad update (float64);
 //   pair_dist_kernel   : the n (n - 1) / 2 pairwise distances of the new particles;
 //   median_kernel      : ONE workgroup: exact bucket select of the two middle order statistics, h_next.  One
-//                        workgroup reads at one CU's rate, so this is for populations of up to a
-//                        couple of hundred particles (cfg2: 100 -> 4,950 distances, 25 us; 200: the whole step
-//                        54 us against 86 with the sort); for larger ones the caller passes h_out = NULL and
-//                        takes the median of the distance buffer with a device-wide sort (500 particles:
-//                        124,750 distances, step 159 us here against 112).
+//                        workgroup reads at one CU's rate, so this is for populations of up to 256 particles
+//                        (cfg2: 100 -> 4,950 distances, 25 us; 200: the whole step 54 us against 86 with a sort);
+//   beyond that (the reference's default is 500 particles = 124,750 distances, mcmc.py:193; the limit here is 4,096
+//   = 8.4 million) the same bucket select runs over the whole chip, three more launches (round 4; rounds 1-3 sorted
+//   the distances with rocPRIM through torch.sort):
+//   pair_dist_kernel   : also reduces min / max of the distances' bit patterns (workgroup, then one atomic each);
+//   hist_kernel        : every workgroup histograms its share over 2,048 linear buckets of [min, max] in LDS and adds
+//                        its non-empty buckets to the global histogram (integer atomics: order-independent);
+//   gather_kernel      : every workgroup finds the bucket(s) holding the two middle ranks from the global histogram
+//                        (the same prefix sum everywhere) and appends its elements of those buckets to a candidate list;
+//   median_cand_kernel : one workgroup: the exact order statistics among the candidates (select_kth again), h_next.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
+#include "step_args.h"
+
 namespace phk {
 
-constexpr int SV_MAXD = 72;    // P + 3 <= 67
-constexpr int SV_MAXB = 4096;  // particles (the kernel row of one particle lives in LDS)
 constexpr int SV_NT = 256;
-
-struct SVArgs {
-    int64_t B;
-    int D;
-    const double* x;      // [B, D]
-    const double* g;      // [B, D] grad log p
-    double* mu;           // [B, D] in/out
-    double* nu;
-    double* nu_max;
-    const double* h_in;   // device scalar
-    double* x_out;        // [B, D]
-    double den1, den2;    // 1 - b1^count, 1 - b2^count
-    double lr, b1, b2, eps;
-};
 
 __global__ __launch_bounds__(SV_NT) void svgd_update_kernel(SVArgs A) {
     __shared__ double xj[SV_MAXD];
@@ -88,21 +82,47 @@ __global__ __launch_bounds__(SV_NT) void svgd_update_kernel(SVArgs A) {
     }
 }
 
+// Scratch of the chip-wide select, behind the two double arrays of the workspace (see svgd_ws_doubles); set up by
+// sel_init_kernel at the start of every step.
+struct SelGlobal {
+    unsigned long long mn, mx;  // min / max bit pattern of the distances (non-negative doubles order like their bits)
+    int ncand;                  // candidates gathered
+    int pad_;
+    long long below;            // elements in buckets before the first gathered one
+    int hist[2048];
+};
+
 // distances of the strict lower triangle, row-major: pair p <-> (i, j), i > j, p = i (i - 1) / 2 + j
-__global__ void pair_dist_kernel(const double* __restrict__ x, int64_t B, int D, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void pair_dist_kernel(const double* __restrict__ x, int64_t B, int D, double* __restrict__ out,
+                                                        SelGlobal* G) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = B * (B - 1) / 2;
-    if (p >= n) return;
-    int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
-    while (i * (i - 1) / 2 > p) --i;
-    while ((i + 1) * i / 2 <= p) ++i;
-    const int64_t j = p - i * (i - 1) / 2;
-    double d2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-        const double df = x[i * D + d] - x[j * D + d];
-        d2 = fma(df, df, d2);
+    unsigned long long key_mn = ~0ull, key_mx = 0ull;
+    if (p < n) {
+        int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+        while (i * (i - 1) / 2 > p) --i;
+        while ((i + 1) * i / 2 <= p) ++i;
+        const int64_t j = p - i * (i - 1) / 2;
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double df = x[i * D + d] - x[j * D + d];
+            d2 = fma(df, df, d2);
+        }
+        const double dist = sqrt(d2);
+        out[p] = dist;
+        key_mn = key_mx = (unsigned long long)__double_as_longlong(dist);
     }
-    out[p] = sqrt(d2);
+    if (G == nullptr) return;  // (wave-uniform: a kernel argument)
+    // min / max over the workgroup: wave shuffles, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(key_mn, off), b = __shfl_xor(key_mx, off);
+        key_mn = a < key_mn ? a : key_mn;
+        key_mx = b > key_mx ? b : key_mx;
+    }
+    if ((threadIdx.x & 63) == 0 && key_mn != ~0ull) {
+        atomicMin(&G->mn, key_mn);
+        atomicMax(&G->mx, key_mx);
+    }
 }
 
 // k-th smallest (0-based) of n non-negative doubles, one workgroup, exact.  Bucket select: min and max of the
@@ -286,18 +306,164 @@ __global__ __launch_bounds__(1024) void median_kernel(const double* __restrict__
     }
 }
 
+// ---- the select over the whole chip (more than SEL_ONE_WG distances) -------------------------------------------
+constexpr int64_t SEL_ONE_WG = 32768;  // distances (256 particles) up to which the single-workgroup select is used (it wins up to ~300 particles)
+
+__device__ __forceinline__ int sel_bucket(double x, double vmn, double scale) {
+    int b = (int)((x - vmn) * scale);
+    return b > SEL_BINS - 1 ? SEL_BINS - 1 : b;
+}
+
+__global__ __launch_bounds__(256) void hist_kernel(const double* __restrict__ v, int64_t n, SelGlobal* G) {
+    __shared__ int h[SEL_BINS];
+    const unsigned long long kmn = G->mn, kmx = G->mx;
+    if (kmn == kmx) return;  // all distances equal: nothing to narrow
+    const double vmn = __longlong_as_double((long long)kmn), vmx = __longlong_as_double((long long)kmx);
+    const double scale = (double)(SEL_BINS - 1) / (vmx - vmn);
+    for (int b = threadIdx.x; b < SEL_BINS; b += 256) h[b] = 0;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) atomicAdd(&h[sel_bucket(v[e], vmn, scale)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < SEL_BINS; b += 256)
+        if (h[b]) atomicAdd(&G->hist[b], h[b]);
+}
+
+// bucket holding global rank k, and the number of elements in the buckets before it (every thread of the workgroup
+// gets both): 256 threads x 8 buckets
+__device__ void rank_bucket(const int* __restrict__ hist, long long k, int* sh, int& bucket, long long& before) {
+    const int t = threadIdx.x;
+    int own = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) own += hist[t * 8 + i];
+    sh[t] = own;
+    __syncthreads();
+    if (t == 0) {  // 256 partial sums: a serial walk, once per workgroup
+        long long acc = 0;
+        int th = 0;
+        for (; th < 255; ++th) {
+            if (k < acc + sh[th]) break;
+            acc += sh[th];
+        }
+        int b = th * 8;
+        for (; b < th * 8 + 7; ++b) {
+            if (k < acc + hist[b]) break;
+            acc += hist[b];
+        }
+        sh[256] = b;
+        sh[257] = (int)(acc & 0xffffffffll);
+        sh[258] = (int)(acc >> 32);
+    }
+    __syncthreads();
+    bucket = sh[256];
+    before = ((long long)sh[258] << 32) | (unsigned int)sh[257];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ v, int64_t n, SelGlobal* G, double* __restrict__ cand) {
+    __shared__ int sh[260];
+    const unsigned long long kmn = G->mn, kmx = G->mx;
+    if (kmn == kmx) return;
+    const double vmn = __longlong_as_double((long long)kmn), vmx = __longlong_as_double((long long)kmx);
+    const double scale = (double)(SEL_BINS - 1) / (vmx - vmn);
+    const double pos = 0.5 * (double)(n - 1);
+    const long long lo = (long long)floor(pos), hi = (long long)ceil(pos);
+    int b_lo, b_hi;
+    long long before_lo, before_hi;
+    rank_bucket(G->hist, lo, sh, b_lo, before_lo);
+    rank_bucket(G->hist, hi, sh, b_hi, before_hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0) G->below = before_lo;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const double x = v[e];
+        const int b = sel_bucket(x, vmn, scale);
+        if (b >= b_lo && b <= b_hi) cand[atomicAdd(&G->ncand, 1)] = x;  // (buckets strictly between the two are empty)
+    }
+}
+
+// one workgroup: median of the n distances from the candidate list (all elements of the bucket(s) holding the two middle
+// ranks; `below` elements lie in earlier buckets), h_out, and the scratch back in its resting state
+__global__ __launch_bounds__(1024) void median_cand_kernel(const double* __restrict__ cand, int64_t n, int64_t B, SelGlobal* G, double* h_out) {
+    __shared__ SelShared S;
+    const unsigned long long kmn = G->mn, kmx = G->mx;
+    const int nc = G->ncand;
+    const long long below = G->below;
+    __syncthreads();
+    const double pos = 0.5 * (double)(n - 1);
+    const int64_t lo = (int64_t)floor(pos), hi = (int64_t)ceil(pos);
+    double vlo, vhi;
+    if (kmn == kmx) {
+        vlo = vhi = __longlong_as_double((long long)kmn);
+    } else {
+        vlo = select_kth(cand, nc, lo - below, S);
+        __syncthreads();
+        vhi = vlo;
+        if (hi != lo) {  // (as in median_kernel, on the candidates: ranks shifted by `below`)
+            if (threadIdx.x == 0) {
+                S.cnt = 0;
+                S.mn = ~0ull;
+            }
+            __syncthreads();
+            const unsigned long long klo = (unsigned long long)__double_as_longlong(vlo);
+            int c = 0;
+            unsigned long long nx = ~0ull;
+            for (int64_t e = threadIdx.x; e < nc; e += blockDim.x) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(cand[e]);
+                if (key <= klo) ++c;
+                else nx = key < nx ? key : nx;
+            }
+            atomicAdd(&S.cnt, c);
+            atomicMin(&S.mn, nx);
+            __syncthreads();
+            vhi = below + (int64_t)S.cnt >= hi + 1 ? vlo : __longlong_as_double((long long)S.mn);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const double med = vlo + (vhi - vlo) * (pos - (double)lo);
+        *h_out = med * med / log((double)B);
+    }
+}
+
+// (every step: the workspace is the caller's and may have held anything in between)
+__global__ void sel_init_kernel(SelGlobal* G) {
+    for (int b = threadIdx.x; b < SEL_BINS; b += blockDim.x) G->hist[b] = 0;
+    if (threadIdx.x == 0) {
+        G->mn = ~0ull;
+        G->mx = 0ull;
+        G->ncand = 0;
+        G->below = 0;
+    }
+}
+
+// doubles of workspace phk_svgd_step needs for B particles: the distances; beyond the single-workgroup limit as many
+// again for the candidate list (a bucket can hold all of them when they are all equal but one) and the SelGlobal block
+int64_t svgd_ws_doubles(int64_t B) {
+    const int64_t n = B * (B - 1) / 2;
+    if (n <= SEL_ONE_WG) return n > 0 ? n : 1;
+    return 2 * n + (int64_t)((sizeof(SelGlobal) + 7) / 8);
+}
+
 hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(svgd_update_kernel, dim3((unsigned)a.B), dim3(SV_NT), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t n = a.B * (a.B - 1) / 2;
+    const bool chip = h_out != nullptr && n > SEL_ONE_WG;
+    SelGlobal* G = chip ? (SelGlobal*)(dist_ws + 2 * n) : nullptr;
+    if (chip) hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(256), 0, st, G);
     if (n > 0) {
-        hipLaunchKernelGGL(pair_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)a.x_out, a.B, a.D, dist_ws);
+        hipLaunchKernelGGL(pair_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)a.x_out, a.B, a.D, dist_ws, G);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (h_out != nullptr) hipLaunchKernelGGL(median_kernel, dim3(1), dim3(1024), 0, st, (const double*)dist_ws, n, a.B, h_out);
+    if (h_out == nullptr) return hipGetLastError();
+    if (!chip) {
+        hipLaunchKernelGGL(median_kernel, dim3(1), dim3(1024), 0, st, (const double*)dist_ws, n, a.B, h_out);
+        return hipGetLastError();
+    }
+    const unsigned wgs = (unsigned)std::min<int64_t>((n + 256 * 8 - 1) / (256 * 8), 2048);
+    hipLaunchKernelGGL(hist_kernel, dim3(wgs), dim3(256), 0, st, (const double*)dist_ws, n, G);
+    hipLaunchKernelGGL(gather_kernel, dim3(wgs), dim3(256), 0, st, (const double*)dist_ws, n, G, dist_ws + n);
+    hipLaunchKernelGGL(median_cand_kernel, dim3(1), dim3(1024), 0, st, (const double*)(dist_ws + n), n, a.B, G, h_out);
     return hipGetLastError();
 }
 

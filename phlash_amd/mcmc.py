@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import parallel, svgd
+from . import parallel, step, svgd
 from .afs import bws_transform, fold_transform
 from .data import init_mcmc_data
 from .kernel import get_kernel
@@ -88,17 +88,33 @@ class _NoRows:
         return under > 0
 
 
-def _join_process_group() -> int:
+def _join_process_group(device=None) -> int:
     """Under torchrun (RANK / WORLD_SIZE in the environment) bind this process to GPU LOCAL_RANK and
     join the process group if the caller has not done so; returns the device ordinal to use.  Without
     this, every rank of a ``torchrun`` launch that simply calls ``fit`` would run the whole, unsharded
-    problem on GPU 0."""
+    problem on GPU 0.  ``device`` (the ``fit(device=...)`` option) overrides every rule below."""
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: phlash_amd.fit needs an MI355X (there is no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if device is not None:
+        torch.cuda.set_device(int(device))
     if dist.is_available() and dist.is_initialized():
-        # the caller set the group up and with it chose a device (one visible GPU per rank, several gloo
-        # ranks on one GPU, ...): respect that choice
+        # The caller set the group up.  If it also chose a device (explicit device= option, one visible GPU
+        # per rank, or it already moved off device 0) that choice stands.  A caller who only ran
+        # init_process_group under torchrun and left the device to fit() -- every rank still on cuda:0 with
+        # several GPUs visible -- gets the LOCAL_RANK pinning a fit() that initialises the group itself would
+        # have applied: otherwise all ranks would share GPU 0 (RCCL: duplicate-GPU error or a hang).
+        ndev = torch.cuda.device_count()
+        wsize = dist.get_world_size()
+        if device is None and wsize > 1 and ndev > 1 and torch.cuda.current_device() == 0 and "LOCAL_RANK" in os.environ:
+            local = int(os.environ["LOCAL_RANK"])
+            if 0 < local < ndev:
+                torch.cuda.set_device(local)
+        if wsize > 1 and dist.get_backend() == "nccl" and ndev > 1 and "LOCAL_RANK" in os.environ \
+                and int(os.environ["LOCAL_RANK"]) != torch.cuda.current_device() and device is None:
+            warnings.warn(f"rank {dist.get_rank()} of an RCCL group runs on cuda:{torch.cuda.current_device()} although "
+                          f"LOCAL_RANK={os.environ['LOCAL_RANK']}: several ranks may be sharing one GPU "
+                          "(pass fit(device=...) to choose explicitly)")
         return torch.cuda.current_device()
     if world > 1:
         if "RANK" not in os.environ:
@@ -132,7 +148,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     Returns:
         list of ``DemographicModel`` (one per particle), rates per base pair.
     """
-    device_index = _join_process_group()
+    device_index = _join_process_group(options.get("device"))
     seed = options.get("key", 1)
     if not isinstance(seed, (int, np.integer)):
         seed = int(np.asarray(seed).ravel()[-1])
@@ -279,15 +295,29 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             it = tqdm.trange(niter, desc="Fitting model")
         except ImportError:
             pass
+    # The step's chain (parameter map -> kernels -> chunk sums + flags -> all-reduce -> prior + chain rule) as a fixed
+    # sequence of HIP launches (phlash_amd.step); ``fused_step=False`` (extension, diagnostic) takes the autograd
+    # definition instead, which is what the fused path is tested against.
+    fused = bool(options.get("fused_step", True)) and step.fusable(template, train_kern)
+    c_host = (1.0, N / S, 1.0)
+
     def grad_logp(state, inds):
         """d log density / d particles for this minibatch [B, D]; ends in exactly one all-reduce."""
         if by_particles:
+            if fused:
+                _, g = parallel.particle_sharded_value_and_grad(
+                    None, state.particles, kern=train_kern,
+                    value_grad_fn=lambda xl: step.log_density_and_grad(template, xl, c_host, train_kern, inds, afs,
+                                                                       afs_transform, reduce=False))
+                return g
             _, g = parallel.particle_sharded_value_and_grad(
                 lambda xl: _log_density_population(xl, template, c_train, train_kern, inds, afs, afs_transform,
                                                    reduce=False),
                 state.particles, kern=train_kern)
             return g
         local = parallel.split_minibatch(inds, rank, size)
+        if fused:
+            return step.log_density_and_grad(template, state.particles, c_host, train_kern, local, afs, afs_transform)[1]
         xs = state.particles.detach().requires_grad_(True)
         lp = _log_density_population(xs, template, c_train, train_kern, local, afs, afs_transform)
         (g,) = torch.autograd.grad(lp.sum(), xs)

@@ -101,22 +101,32 @@ def shard_mode(minibatch_size: int, size: int, requested: str = "auto") -> str:
     return "chunks" if minibatch_size >= size else "particles"
 
 
-def particle_sharded_value_and_grad(logp_fn, x: torch.Tensor, kern=None):
-    """logp_fn(x_local [Bl, D]) -> [Bl] (differentiable).  Every rank evaluates particles
+def particle_sharded_value_and_grad(logp_fn, x: torch.Tensor, kern=None, value_grad_fn=None):
+    """logp_fn(x_local [Bl, D]) -> [Bl] (differentiable), or value_grad_fn(x_local) -> (logp [Bl], grad [Bl, D])
+    (the fused step, phlash_amd.step.log_density_and_grad with reduce=False, which leaves the flags of its
+    evaluation in ``kern._flags``).  Every rank evaluates particles
     rank, rank+W, ...; returns (logp [B], grad [B, D]) identical on all ranks, assembled with ONE
     all-reduce of a zero-padded [B + 1, 1 + D] buffer (row B: the flags of ``kern``, the kernel object
     ``logp_fn`` evaluates with, so that the ranks agree on a redo)."""
     rank, size = world()
     B, D = x.shape
     idx = torch.arange(rank, B, size, device=x.device)
-    xl = x.detach()[idx].requires_grad_(True)
     buf = torch.zeros((B + 1, 1 + D), dtype=x.dtype, device=x.device)
+    flags_moved = False
     if idx.numel():
-        lp = logp_fn(xl)
-        (g,) = torch.autograd.grad(lp.sum(), xl)
+        if value_grad_fn is not None:
+            lp, g = value_grad_fn(x.detach()[idx])
+            flags_moved = getattr(kern, "_flags", None) is not None
+            if flags_moved:  # the fused evaluation already took the flags off the device word
+                buf[B, :2] = kern._flags
+                kern._flags = buf[B, :2]
+        else:
+            xl = x.detach()[idx].requires_grad_(True)
+            lp = logp_fn(xl)
+            (g,) = torch.autograd.grad(lp.sum(), xl)
         buf[idx, 0] = lp.detach()
         buf[idx, 1:] = g
-    if kern is not None and x.is_cuda:
+    if kern is not None and x.is_cuda and not flags_moved:
         _take_flags(kern, buf[B, :2])
     all_reduce_sum_(buf)
     return buf[:B, 0], buf[:B, 1:]

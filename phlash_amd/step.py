@@ -1,0 +1,94 @@
+"""The sampler's inner step without autograd: log density of every particle and its gradient in particle space
+in a fixed sequence of HIP launches.
+
+What ``jax.grad(log_density)`` under ``vmap`` is in the reference (src/phlash/mcmc.py:275-286 through
+model.py:24-73, params.py:33-127, transition.py:37-85) is here
+
+    phk_param_map_rounded   x [B, D] -> params [B, 7, K] (float64, and rounded to the kernels' float type) + Jacobian
+    phk_loglik              forward / backward kernels over the minibatch  -> ll [B, S], d ll / d params [B, S, 7, K]
+    phk_reduce_chunks       sums over the minibatch + the kernel object's flags -> buf [B + 1, 1 + 7K]
+    (one all-reduce of buf over the ranks)
+    phk_chain_rule          prior + J^T (d ll / d params) (+ the AFS term's value and gradient) -> logp [B], grad [B, D]
+
+instead of the same arithmetic spread over ~25 small torch launches (stack / cast / sum / buffer assembly / flag
+hand-over / prior / autograd's backward graph: 0.3 ms of a 5.5 ms step at the reference's production shape,
+profiles/r03_ab_experiments.txt item 18c).  ``model.log_density`` / ``mcmc._log_density_population`` (autograd)
+stay as the definition this is tested against (tests/test_kernel_api.py).  The AFS term (n > 2 samples) is
+evaluated by its own small autograd graph and enters ``phk_chain_rule`` as ``extra_val`` / ``extra_grad``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, parallel
+from .params import MCMCParams
+from .util import get_pattern
+
+F64 = torch.float64
+
+
+def fusable(template: MCMCParams, kern) -> bool:
+    """The fused path needs the compiled state count (no padding columns in the gradient) and a GPU kernel object."""
+    eng = getattr(kern, "_eng", None)
+    return eng is not None and eng.K_user == eng.K == get_pattern(template.pattern).M
+
+
+def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_inds, afs=None, afs_transform=None,
+                         reduce: bool = True):
+    """(logp [B], d logp / d x [B, D]) for particles ``x`` [B, D] on the kernel's GPU.
+
+    ``c`` = weights of (prior, HMM term, AFS term) (model.py:69-72); ``local_inds``: this rank's share of the
+    minibatch (may be empty); ``reduce``: all-reduce the HMM buffer over the ranks (chunk mode) -- with
+    ``reduce=False`` (particle mode) the flags stay local in ``kern._flags`` for the caller's own collective."""
+    lib = _lib.load()
+    eng = kern._eng
+    dev = kern.device
+    x = x.detach().to(device=dev, dtype=F64).contiguous()
+    B, D = x.shape
+    pat = get_pattern(template.pattern)
+    K, P = pat.M, len(pat)
+    assert D == P + 3 and fusable(template, kern)
+    epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    params = torch.empty((B, 1, 7, K), dtype=F64, device=dev)
+    jac = torch.empty((B, 7 * K, D), dtype=F64, device=dev)
+    p32 = None if eng.double_precision else torch.empty((B, 1, 7, K), dtype=torch.float32, device=dev)
+    _lib.check(lib.phk_param_map_rounded(dev.index, K, P, epoch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                         float(template.theta), x.data_ptr(), B, params.data_ptr(), jac.data_ptr(),
+                                         p32.data_ptr() if p32 is not None else None, stream))
+    if isinstance(local_inds, torch.Tensor):
+        inds = local_inds.to(device=dev, dtype=torch.int64)
+    else:
+        inds = kern._inds_tensor(local_inds)
+    buf = torch.empty((B + 1, 1 + 7 * K), dtype=F64, device=dev)
+    if inds.numel():
+        ll, g = eng.run(params if p32 is None else p32, inds, warmup=kern.overlap, grad=True, dlog=False)
+        _lib.check(lib.phk_reduce_chunks(eng._h, ll.data_ptr(), g.data_ptr(), B, inds.numel(), buf.data_ptr(), stream))
+    else:  # a rank without a share of this minibatch contributes zeros (and its flags)
+        buf.zero_()
+        eng.take_flags_async(buf[B, :2])
+    kern._flags = buf[B, :2]  # where check_rescaling(collective=True) / begin_check read the (reduced) flags
+    if reduce:
+        parallel.all_reduce_sum_(buf)
+    # (host numbers; a device tensor works but costs a synchronisation)
+    c0, c1, c2 = (float(v) for v in (c.tolist() if isinstance(c, torch.Tensor) else c))
+    extra_val = extra_grad = None
+    if afs is not None and len(afs) > 1:
+        from .model import afs_term
+
+        xa = x.detach().requires_grad_(True)
+        l3 = afs_term(template.from_flat(xa).to_dm(), afs, afs_transform)
+        (extra_grad,) = torch.autograd.grad(l3.sum(), xa)
+        extra_val, extra_grad = l3.detach().contiguous(), extra_grad.contiguous()
+    logp = torch.empty(B, dtype=F64, device=dev)
+    grad = torch.empty((B, D), dtype=F64, device=dev)
+    _lib.check(lib.phk_chain_rule(dev.index, K, P, float(template.alpha), float(template.beta), x.data_ptr(),
+                                  buf.data_ptr(), jac.data_ptr(), B, c0, c1,
+                                  extra_val.data_ptr() if extra_val is not None else None,
+                                  extra_grad.data_ptr() if extra_grad is not None else None, c2,
+                                  logp.data_ptr(), grad.data_ptr(), stream))
+    return logp, grad

@@ -15,7 +15,7 @@ posteriors instead (tests/test_svgd.py).
   corrected second moment, update = -lr * m_hat / (sqrt(v_max) + eps).
 
 The functions below are the definition (plain torch, CPU-testable).  On the GPU ``step`` runs the same
-update as three HIP launches (``phk_svgd_step``, csrc/svgd_step.hip) instead of ~70 small torch kernels;
+update as a handful of HIP launches (``phk_svgd_step``, csrc/svgd_step.hip) instead of ~70 small torch kernels;
 ``tests/test_kernel_api.py::test_svgd_step_kernel_matches_the_torch_definition`` holds the two together.
 """
 
@@ -84,7 +84,9 @@ def step_torch(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDStat
 
 
 def step_hip(state: SVGDState, grad_logp: torch.Tensor, lr: float, b1=0.9, b2=0.999, eps=1e-8) -> SVGDState:
-    """The same update on the GPU through the C ABI (three launches, no host synchronisation)."""
+    """The same update on the GPU through the C ABI (three launches up to 256 particles, seven beyond: the median of
+    up to 8.4 million pairwise distances is an exact bucket select over the whole chip; no host synchronisation, no
+    sort)."""
     from . import _lib
 
     x = state.particles.contiguous()
@@ -94,26 +96,19 @@ def step_hip(state: SVGDState, grad_logp: torch.Tensor, lr: float, b1=0.9, b2=0.
     mu, nu, nu_max = state.mu.clone(), state.nu.clone(), state.nu_max.clone()
     x_out = torch.empty_like(x)
     h_in = state.length_scale.to(dtype=torch.float64, device=x.device).reshape(1).contiguous()
-    n_pairs = B * (B - 1) // 2
-    in_kernel = n_pairs <= _MEDIAN_IN_KERNEL  # one workgroup selects the median: small populations only
     h_out = torch.empty(1, dtype=torch.float64, device=x.device)
-    ws = torch.empty(max(n_pairs, 1), dtype=torch.float64, device=x.device)
+    lib = _lib.load()
+    ws = torch.empty(int(lib.phk_svgd_workspace_doubles(B)), dtype=torch.float64, device=x.device)
     count = state.count + 1
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(_lib.load().phk_svgd_step(
+    _lib.check(lib.phk_svgd_step(
         x.device.index, B, D, x.data_ptr(), g.data_ptr(), mu.data_ptr(), nu.data_ptr(), nu_max.data_ptr(),
-        h_in.data_ptr(), h_out.data_ptr() if in_kernel else None, x_out.data_ptr(), ws.data_ptr(), count, float(lr),
+        h_in.data_ptr(), h_out.data_ptr(), x_out.data_ptr(), ws.data_ptr(), count, float(lr),
         b1, b2, eps, ctypes.c_void_p(stream)))
-    if not in_kernel:
-        # the kernel left the pairwise distances in ws: median by a device-wide sort (torch.quantile sorts too,
-        # but also checks its input for NaN on the host -- a synchronisation in the middle of the step)
-        srt = torch.sort(ws).values
-        med = 0.5 * (srt[(n_pairs - 1) // 2] + srt[n_pairs // 2])
-        h_out = med * med / math.log(B)
     return SVGDState(particles=x_out, length_scale=h_out.reshape(()), mu=mu, nu=nu, nu_max=nu_max, count=count)
 
 
-_MEDIAN_IN_KERNEL = 32768  # pairwise distances (256 particles) up to which the single-workgroup select is used (it wins up to ~300)
+_MEDIAN_IN_KERNEL = 32768  # pairwise distances (256 particles) up to which ONE workgroup selects the median; beyond: the chip-wide select (csrc/svgd_step.hip)
 
 
 def step(state: SVGDState, grad_logp: torch.Tensor, lr: float) -> SVGDState:

@@ -301,3 +301,83 @@ def test_cfg3_afs_term_on_the_gpu_against_oracle():
             fd = (oracle_val(X[b] + e) - oracle_val(X[b] - e)) / 2e-5
             assert abs(float(g[b, dcoord]) - fd) <= 1e-5 * max(1.0, abs(fd)), (b, dcoord, float(g[b, dcoord]), fd)
     assert float(g[:, -1].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,dbl,B,S", [(16, False, 5, 3), (16, True, 9, 40), (32, False, 3, 1), (64, True, 2, 7), (16, False, 2, 2500)])
+def test_phk_reduce_chunks_against_numpy(K, dbl, B, S):
+    """``phk_reduce_chunks``: sums over the minibatch axis of ll [B, S] and d ll / d params [B, S, 7, K] in the
+    buffer layout that is all-reduced ([B + 1, 1 + 7K], row B = flags), against numpy sums.  Inputs are random
+    arrays (the kernel is a fixed-order sum, independent of where they come from); the flag row is exercised on a
+    real kernel object: a chunk index out of range raises bit 1 of its device word."""
+    from phlash_amd.engine import HipEngine
+
+    L, lib = _lib()
+    rng = np.random.default_rng(K + S)
+    data = (rng.uniform(size=(3, 64)) < 0.1).astype(np.int8)
+    eng = HipEngine(K, data, double_precision=dbl, device=0)
+    ll = rng.normal(size=(B, S)) * 1e3
+    g = rng.normal(size=(B, S, 7, K)) * np.exp(rng.normal(size=(B, S, 7, 1)) * 3)
+    g = g.astype(np.float64 if dbl else np.float32)
+    tl, tg = torch.tensor(ll, device="cuda"), torch.tensor(g, device="cuda")
+    buf = torch.full((B + 1, 1 + 7 * K), float("nan"), dtype=torch.float64, device="cuda")
+    L.check(lib.phk_reduce_chunks(eng._h, tl.data_ptr(), tg.data_ptr(), B, S, buf.data_ptr(), _stream()))
+    got = buf.cpu().numpy()
+    np.testing.assert_allclose(got[:B, 0], ll.sum(1), rtol=1e-13, atol=1e-10)
+    want = g.astype(np.float64).sum(1).reshape(B, -1)
+    np.testing.assert_allclose(got[:B, 1:], want, rtol=1e-12, atol=1e-12 * np.abs(g).max())
+    assert (got[B] == 0).all()  # no flag raised
+    # a bad chunk index: the forward kernel clamps it and raises FLAG_BAD_INDEX; reduce_chunks hands it over and clears it
+    P = _params_block(K, 2)
+    pt = torch.tensor(P[:, None], device="cuda", dtype=torch.float64 if dbl else torch.float32)
+    ll2, g2 = eng.run(pt.double(), torch.tensor([0, 7], device="cuda"), grad=True)
+    buf2 = torch.empty((3, 1 + 7 * K), dtype=torch.float64, device="cuda")
+    L.check(lib.phk_reduce_chunks(eng._h, ll2.data_ptr(), g2.data_ptr(), 2, 2, buf2.data_ptr(), _stream()))
+    assert buf2[2, :2].tolist() == [0.0, 1.0] and float(buf2[2, 2:].abs().sum()) == 0.0
+    L.check(lib.phk_reduce_chunks(eng._h, ll2.data_ptr(), g2.data_ptr(), 2, 2, buf2.data_ptr(), _stream()))
+    assert buf2[2, :2].tolist() == [0.0, 0.0]  # the word was cleared by the first hand-over
+    eng.close()
+
+
+def _params_block(K, B, seed=3):
+    """[B, 7, K] valid parameter blocks from the numpy oracle's map (sigma = 0.3 population)"""
+    pat, _, X = _population(K, B, seed, sigma=0.09)
+    return np.stack([o.from_dm(o.particle_to_dm(xb, pat, 1e-2)).stack() for xb in X])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,extra", [(16, False), (16, True), (32, True), (64, False)])
+def test_phk_chain_rule_against_numpy(K, extra):
+    """``phk_chain_rule``: logp = c0 log_prior + c1 buf[:, 0] + c2 extra_val and its gradient c0 d log_prior + c1 J^T buf[:, 1:]
+    + c2 extra_grad, against numpy (prior value from the numpy oracle, its gradient from ``phk_log_prior``, which has
+    its own test against finite differences of the oracle); a non-finite particle gets -inf and a zero gradient row."""
+    L, lib = _lib()
+    B = 11
+    pat, P, X = _population(K, B, seed=7 * K)
+    D = P + 3
+    rng = np.random.default_rng(K)
+    buf = rng.normal(size=(B + 1, 1 + 7 * K)) * 50
+    jac = rng.normal(size=(B, 7 * K, D))
+    ev, eg = rng.normal(size=B), rng.normal(size=(B, D))
+    buf[4, 0] = np.nan  # particle 4: log-likelihood not finite
+    alpha, beta, c0, c1, c2 = 0.3, 0.02, 1.0, 37.5, 0.7
+    x = torch.tensor(X, device="cuda")
+    tb, tj = torch.tensor(buf, device="cuda"), torch.tensor(jac, device="cuda")
+    tev, teg = torch.tensor(ev, device="cuda"), torch.tensor(eg, device="cuda")
+    logp = torch.empty(B, dtype=torch.float64, device="cuda")
+    grad = torch.empty((B, D), dtype=torch.float64, device="cuda")
+    L.check(lib.phk_chain_rule(0, K, P, alpha, beta, x.data_ptr(), tb.data_ptr(), tj.data_ptr(), B, c0, c1,
+                               tev.data_ptr() if extra else None, teg.data_ptr() if extra else None, c2,
+                               logp.data_ptr(), grad.data_ptr(), _stream()))
+    pv = torch.empty(B, dtype=torch.float64, device="cuda")
+    pg = torch.empty((B, D), dtype=torch.float64, device="cuda")
+    L.check(lib.phk_log_prior(0, P, alpha, beta, x.data_ptr(), B, pv.data_ptr(), pg.data_ptr(), _stream()))
+    prior = np.array([o.log_prior(xb, pat, alpha, beta) for xb in X])
+    want_lp = c0 * prior + c1 * buf[:B, 0] + (c2 * ev if extra else 0.0)
+    want_g = c0 * pg.cpu().numpy() + c1 * np.einsum("bj,bjd->bd", buf[:B, 1:], jac) + (c2 * eg if extra else 0.0)
+    got_lp, got_g = logp.cpu().numpy(), grad.cpu().numpy()
+    ok = np.arange(B) != 4
+    np.testing.assert_allclose(got_lp[ok], want_lp[ok], rtol=1e-12)
+    scale = np.abs(want_g[ok]).max(-1, keepdims=True)
+    assert float((np.abs(got_g[ok] - want_g[ok]) / scale).max()) < 1e-13
+    assert got_lp[4] == -np.inf and (got_g[4] == 0).all()

@@ -548,16 +548,16 @@ def test_dense_kernels_random_shapes(seed):
     """The one-state-per-lane kernels (K = 16, float32, rescale interval 4: dense M_h^16 ... M_h^2 steps, lean
     piece loops for whole 64-site pieces, general loop at the row ends and around the warm-up boundary) on
     seeded random draws of everything their control flow depends on: row length 1 ... 3,000 (no whole
-    piece, exactly whole pieces, ragged), warm-up boundary anywhere, het rate 0 ... 5 %, runs of missing
+    piece, exactly whole pieces, ragged), warm-up boundary anywhere, het rate 0 ... 30 %, runs of missing
     sites, a batch that leaves lane groups of the last wave without a sequence, checkpoint interval 8 / 16,
     and the launch form (serial sweep behind the dense forward kernel; segmented: dense forward kernel
     beside the dense beta scan; hybrid with a random split) -- against the float64 oracle."""
     rng = np.random.default_rng(5000 + seed)
     L = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 127, 128, 512, 513, 1024, int(rng.integers(1, 3001)), int(rng.integers(1, 3001))]))
     W = int(rng.choice([0, 0, int(rng.integers(0, L + 1)), L, max(L - 1, 0), min(64, L), min(63, L), min(65, L)]))
-    B, S = int(rng.integers(1, 8)), int(rng.integers(1, 6))
+    B, S = int(rng.integers(1, 14)), int(rng.integers(1, 6))  # (B >= 4: waves whose four sequences share their row -- the scalar-code path)
     N = S + int(rng.integers(0, 3))
-    het = float(rng.choice([0.0, 0.005, 0.02, 0.05]))
+    het = float(rng.choice([0.0, 0.005, 0.02, 0.05, 0.1, 0.3]))
     data = (rng.uniform(size=(N, L)) < het).astype(np.int8)
     for r in range(N):
         for _ in range(int(rng.integers(0, 3))):

@@ -1,6 +1,8 @@
 """CPU tests of the product's host-side math (torch float64) against the oracle (numpy loops) and
 against the reference tests' identities.  No GPU, no HIP library calls."""
 
+import os
+
 import numpy as np
 import pytest
 import scipy.linalg
@@ -236,3 +238,39 @@ def test_stack_of_unstacked_rows_is_the_same_tensor():
     assert PSMCParams(*[torch.ones(3) for _ in range(7)]).stack().shape == (7, 3)
     swapped = pp._replace(b=pp.d, d=pp.b)  # rows of the same tensor in another order
     assert torch.equal(swapped.stack()[:, 0], y[:, 1])
+
+
+# ---- the product's host pieces against REFERENCE-EXECUTED vectors (oracle/make_ref_host_golden.py: the reference's
+# ---- own _W_matrix / Pattern / _chunk_het_matrix text, read with ast and run with numpy only) -------------------
+def _host_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host_golden.npz"))
+
+
+def test_W_matrix_equals_reference_executed():
+    G = _host_golden()
+    for n in range(2, 41):
+        np.testing.assert_array_equal(_W_matrix(n), G[f"W_{n}"])
+
+
+def test_pattern_equals_reference_executed():
+    G = _host_golden()
+    for i, p in enumerate(G["patterns_ok"]):
+        pat = Pattern(str(p))
+        assert list(pat.widths) == G[f"pattern_{i}_epochs"].tolist()
+        assert [pat.M, len(pat)] == G[f"pattern_{i}_M_len"].tolist()
+        vals = list(range(100, 100 + len(pat)))
+        assert pat.expand(vals) == G[f"pattern_{i}_expand"].tolist()
+        assert pat.expand(torch.tensor(vals)).tolist() == G[f"pattern_{i}_expand"].tolist()
+    for p in G["patterns_bad"]:
+        with pytest.raises(ValueError):
+            Pattern(str(p))
+
+
+def test_chunk_layout_equals_reference_executed():
+    from oracle.make_ref_host_golden import chunk_input
+
+    G = _host_golden()
+    for i, (n, L, ov, cs, seed) in enumerate(G["chunk_cases"].tolist()):
+        got = chunk_het_matrix(chunk_input(n, L, seed), ov, cs)
+        assert got.dtype == np.int8
+        np.testing.assert_array_equal(got, G[f"chunk_{i}"])

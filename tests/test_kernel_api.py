@@ -319,3 +319,45 @@ def test_log_prior_kernel_matches_the_torch_definition(P, alpha, beta):
     np.testing.assert_allclose(g.cpu(), gref * w[:, None], rtol=1e-10, atol=1e-12)
     with torch.no_grad():
         np.testing.assert_allclose(log_prior_population(template, x.cuda()).cpu(), ref.detach(), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("dbl", [True, False])
+@pytest.mark.parametrize("with_afs", [False, True])
+def test_fused_step_matches_the_autograd_definition(rng, dbl, with_afs):
+    """``phlash_amd.step.log_density_and_grad`` (parameter map -> kernels -> phk_reduce_chunks -> phk_chain_rule, no
+    autograd) against ``mcmc._log_density_population`` differentiated by autograd (the definition): value and
+    particle-space gradient, with and without the AFS term, with an empty minibatch share, and the flag hand-over."""
+    from phlash_amd import mcmc, step
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.params import MCMCParams
+
+    W, L = 40, 700
+    chunks = (rng.uniform(size=(9, W + L)) < 0.07).astype(np.int8)
+    chunks[2, 100:130] = -1
+    pat = "14*1+1*2"
+    init = MCMCParams.from_linear(pat, 1e-4, 15.0, np.ones(15), 1e-2, 1e-2, alpha=0.05, beta=0.003)
+    template = MCMCParams(pattern=init.pattern, t_tr=None, c_tr=None, rho_over_theta_tr=None, theta=init.theta,
+                          alpha=init.alpha, beta=init.beta)
+    kern = get_kernel(16, chunks, dbl, overlap=W)
+    dev = kern.device
+    X = (init.flat[None] + 0.4 * torch.tensor(rng.normal(size=(13, 18)))).to(dev)
+    afs = 1e3 / np.arange(1, 12) if with_afs else np.ones(1)
+    c = (1.0, 9.0 / 4, 1.0)
+    ct = torch.tensor(c, dtype=F64, device=dev)
+    assert step.fusable(template, kern)
+    for inds in (np.array([5, 0, 5, 8]), np.array([], dtype=np.int64)):
+        xs = X.clone().requires_grad_(True)
+        lp = mcmc._log_density_population(xs, template, ct, kern, inds, afs, None)
+        (g,) = torch.autograd.grad(lp.sum(), xs)
+        kern._flags = None
+        lp2, g2 = step.log_density_and_grad(template, X, c, kern, inds, afs, None)
+        assert kern._flags is not None and kern._flags.tolist() == [0.0, 0.0]
+        # (same kernels, same inputs: the two differ by the order of a few float64 sums)
+        np.testing.assert_allclose(lp2.cpu().numpy(), lp.detach().cpu().numpy(), rtol=1e-13)
+        scale = g.abs().max(-1, keepdim=True).values
+        assert float(((g2 - g).abs() / scale).max()) < 1e-11
+    # the flags of the evaluation ride in the buffer: a chunk index out of range shows up in kern._flags[1]
+    step.log_density_and_grad(template, X, c, kern, torch.tensor([1, 99], device=dev), afs, None)
+    assert kern._flags.tolist() == [0.0, 1.0]
+    with pytest.raises(AssertionError):
+        kern.check_rescaling(collective=True)

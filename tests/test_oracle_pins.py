@@ -207,3 +207,44 @@ def test_indicative_values_from_survey(pp):
         d = (np.random.default_rng(seed).uniform(size=(10, 1000)) < 0.05).astype(np.int8)
         assert d[0].sum() == nhet
         np.testing.assert_allclose(o.psmc_ll(pp, d[0])[1], ll, rtol=1e-11)
+
+
+# ---- reference-EXECUTED vectors for the pure-Python host pieces (oracle/make_ref_host_golden.py) ---------------
+def _host_golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_host_golden.npz"))
+
+
+def test_oracle_W_matrix_equals_reference_executed():
+    """size_history.py:350-369 run as is (ast + exec, numpy/fractions only): n = 2..40, bit for bit."""
+    from oracle import afs_numpy as oafs
+
+    G = _host_golden()
+    for n in range(2, 41):
+        np.testing.assert_array_equal(oafs.W_matrix(n), G[f"W_{n}"])
+
+
+def test_oracle_pattern_equals_reference_executed():
+    """util.py:8-37 run as is: epochs, M, len and expand for a dozen patterns; the malformed ones raise."""
+    G = _host_golden()
+    for i, p in enumerate(G["patterns_ok"]):
+        ep = o.parse_pattern(str(p))
+        assert ep == G[f"pattern_{i}_epochs"].tolist()
+        assert [sum(ep), len(ep)] == G[f"pattern_{i}_M_len"].tolist()
+        np.testing.assert_array_equal(o.expand_pattern(ep, list(range(100, 100 + len(ep)))), G[f"pattern_{i}_expand"])
+    for p in G["patterns_bad"]:
+        with pytest.raises(ValueError):
+            o.parse_pattern(str(p))
+
+
+def test_oracle_chunk_layout_equals_reference_executed():
+    """data.py:37-61 run as is: the Q7 tail-drop case (10,000 / 4,567 / 123), ragged and degenerate shapes,
+    values outside [-1, 1] (clipped)."""
+    from oracle.make_ref_host_golden import chunk_input
+
+    G = _host_golden()
+    for i, (n, L, ov, cs, seed) in enumerate(G["chunk_cases"].tolist()):
+        got = o.chunk_het_matrix(chunk_input(n, L, seed), ov, cs)
+        assert got.dtype == np.int8
+        np.testing.assert_array_equal(got, G[f"chunk_{i}"])
