@@ -1,7 +1,8 @@
 // Two translation units per (real, K): compiled with -DPHK_REAL=float|double -DPHK_K=<K> -DPHK_SUFFIX=f32_16 ... and
 // -DPHK_PART=1 (forward kernel) or -DPHK_PART=2 (beta scan, backward kernel, finalize), so
-// that the variants build in parallel and each half gets its own compiler flags (see the Makefile).  Without PHK_PART
-// both halves are compiled into one object.  Dispatches (R, T) to the template instantiations of psmc_kernels.hip.
+// that the variants build in parallel and each part gets its own compiler flags (see the Makefile); for float K = 16
+// a third, -DPHK_PART=3, holds the one-state-per-lane forward kernel and beta scan (see PHK_LAT_PART below).  Without
+// PHK_PART everything is compiled into one object.  Dispatches (R, T) to the template instantiations of psmc_kernels.hip.
 #include "psmc_kernels.hip"
 
 #ifndef PHK_REAL
@@ -13,6 +14,15 @@
 #endif
 #define PHK_FWD_PART (PHK_PART == 0 || PHK_PART == 1)
 #define PHK_BWD_PART (PHK_PART == 0 || PHK_PART == 2)
+// PHK_PART == 3 (float, K = 16 only; -DPHK_LAT_SPLIT=1 tells parts 1 and 2 that it exists): the one-state-per-lane
+// forward kernel and beta scan, the latency-bound pair of the small-batch plans.  Their control flow is wave-uniform
+// (scalar observation codes) and branch-heavy, and a taken branch costs a lone wave ~40 cycles, so this part is
+// compiled with -mllvm -structurizecfg-skip-uniform-regions (see the Makefile): the structurizer otherwise turns
+// every multi-way uniform branch into a chain of flag tests with several taken branches per case.
+#ifndef PHK_LAT_SPLIT
+#define PHK_LAT_SPLIT 0
+#endif
+#define PHK_LAT_PART (PHK_PART == 3)
 
 #define PHK_CAT2(a, b) a##b
 #define PHK_CAT(a, b) PHK_CAT2(a, b)
@@ -32,7 +42,7 @@ static size_t lds_bytes(int R, int nt) {
     return (size_t)raw * nt * sizeof(real_t);
 }
 
-#if PHK_FWD_PART
+#if PHK_FWD_PART || PHK_LAT_PART
 template <int R, int T, int NRM>
 static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
@@ -88,7 +98,7 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
 }
 
 #endif
-#if PHK_BWD_PART
+#if PHK_BWD_PART || PHK_LAT_PART
 template <int R, int NRM>
 static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
@@ -109,7 +119,7 @@ constexpr bool f64_fwd_ok(int R) { return sizeof(real_t) == 4 || KK / R <= 8 || 
 template <int R, int T>
 constexpr bool variant_ok() { return KK % R == 0 && KK / R <= 16 && R <= KK && (T == 8 || KK / R <= 4) && f64_fwd_ok(R); }
 
-#if PHK_FWD_PART
+#if PHK_FWD_PART || PHK_LAT_PART
 template <int R, int T>
 static hipError_t fwd_rt(int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     if constexpr (!variant_ok<R, T>()) {
@@ -139,7 +149,7 @@ static hipError_t bwd_rt(int nrm, const KArgs& a, int units, int nt, hipStream_t
     }
 }
 #endif
-#if PHK_BWD_PART
+#if PHK_BWD_PART || PHK_LAT_PART
 template <int R>
 static hipError_t bscan_r(int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
     if constexpr (!variant_ok<R, 8>()) {
@@ -153,7 +163,7 @@ static hipError_t bscan_r(int nrm, const KArgs& a, int64_t seg_sites, void* bseg
 }
 
 #endif
-#if PHK_FWD_PART
+#if PHK_FWD_PART || PHK_LAT_PART
 template <int R>
 static hipError_t fwd_r(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     if (T == 8) return fwd_rt<R, 8>(nrm, ckpt, a, nt, st);
@@ -170,6 +180,20 @@ static hipError_t bwd_r(int T, int nrm, const KArgs& a, int units, int nt, hipSt
 }
 
 #endif
+#if PHK_LAT_SPLIT || PHK_LAT_PART
+hipError_t PHK_CAT(launch_fwd_lat_, PHK_SUFFIX)(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st);
+hipError_t PHK_CAT(launch_bscan_lat_, PHK_SUFFIX)(int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt,
+                                                  hipStream_t st);
+#endif
+#if PHK_LAT_PART
+hipError_t PHK_CAT(launch_fwd_lat_, PHK_SUFFIX)(int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
+    return fwd_r<16>(T, nrm, ckpt, a, nt, st);
+}
+hipError_t PHK_CAT(launch_bscan_lat_, PHK_SUFFIX)(int nrm, const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt,
+                                                  hipStream_t st) {
+    return bscan_r<16>(nrm, a, seg_sites, bseg, fseg, nt, st);
+}
+#endif
 #if PHK_FWD_PART
 hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     switch (R) {
@@ -177,7 +201,11 @@ hipError_t PHK_CAT(launch_fwd_, PHK_SUFFIX)(int R, int T, int nrm, bool ckpt, co
         case 2: return fwd_r<2>(T, nrm, ckpt, a, nt, st);
         case 4: return fwd_r<4>(T, nrm, ckpt, a, nt, st);
         case 8: return fwd_r<8>(T, nrm, ckpt, a, nt, st);
+#if PHK_LAT_SPLIT
+        case 16: return PHK_CAT(launch_fwd_lat_, PHK_SUFFIX)(T, nrm, ckpt, a, nt, st);
+#else
         case 16: return fwd_r<16>(T, nrm, ckpt, a, nt, st);
+#endif
     }
     return hipErrorInvalidValue;
 }
@@ -202,7 +230,11 @@ hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, in
         case 2: return bscan_r<2>(nrm, a, seg_sites, bseg, fseg, nt, st);
         case 4: return bscan_r<4>(nrm, a, seg_sites, bseg, fseg, nt, st);
         case 8: return bscan_r<8>(nrm, a, seg_sites, bseg, fseg, nt, st);
+#if PHK_LAT_SPLIT
+        case 16: return PHK_CAT(launch_bscan_lat_, PHK_SUFFIX)(nrm, a, seg_sites, bseg, fseg, nt, st);
+#else
         case 16: return bscan_r<16>(nrm, a, seg_sites, bseg, fseg, nt, st);
+#endif
     }
     return hipErrorInvalidValue;
 }

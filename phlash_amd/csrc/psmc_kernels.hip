@@ -244,6 +244,9 @@ __device__ __forceinline__ float dense16(float x, const float (&d)[16]) {
 // (see the particle-major mapping in fwd_kernel), so the codes are scalars.  Before, a het cost two structured steps
 // (~35 instructions each for a lone wave), a broken hom run and two rescales: the reference's production shape lost
 // 26 % (5 % hets) to 55 % (10 %) of its rate against 1 %-het rows (profiles/r03_ab_experiments.txt item 18).
+#ifndef PHK_DENSE_RESCALE_SITES
+#define PHK_DENSE_RESCALE_SITES 64  // dense steps: rescale once the debt (1 per hom site, 16 per het / missing site of the scalar-code path) reaches this
+#endif
 #ifndef PHK_DENSE_UNI
 #define PHK_DENSE_UNI 1  // A/B: 0 = waves with one observation row take the wave-vote path like any other
 #endif
@@ -578,6 +581,99 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         }
     }
 
+    // ---- eight sites whose codes are a wave-uniform 16-bit word h (site i = bits [2i, 2i+2)) ----------------------
+    // Measured on the MI355X (scripts/microbench/latency.hip, one wave alone on its SIMD): a VALU instruction issues
+    // every ~6.5 cycles whether or not it depends on the one before, a dense step is 94 cycles, a rescale 72, and a
+    // TAKEN branch ~40 -- six instructions' worth.  So the shapes that matter get straight-line code behind ONE
+    // dispatch: all hom (one dense step), and exactly one het / missing site at position p (two dense steps and a
+    // multiply, 8-way switch on p).  Anything else takes the run loop (a dispatch per run).
+    // Forward form (FWD): sites 0 .. 7 in order, x <- x M_h^(p+1) .* ratio, then M_h^(7-p).
+    // Beta-scan form: sites 7 .. 0, x <- M_h^(p+1) (ratio .* (M_h^(7-p) x)).
+    // Returns the rescale debt of the half (1 per hom site, 16 per het / missing site); `resc(x)` is called after a run
+    // of the generic loop whenever the running debt (debt0 + so far) reaches the threshold: it rescales x, books the
+    // exponent and returns the debt it leaves (0).
+    template <bool FWD, typename Resc>
+    __device__ __forceinline__ int half_step(float& x, const uint32_t h, const int debt0, Resc&& resc) const {
+        if constexpr (has_dense<real, K, R>()) {
+            if (__builtin_expect(h == 0u, 1)) {
+                x = dense16(x, this->P[7]);
+                return debt0 + 8;
+            }
+            const uint32_t m = (h | (h >> 1)) & 0x5555u;  // bit 2i set: site i is not hom
+            if (__builtin_expect((m & (m - 1u)) == 0u, 1)) {
+                const int p = __builtin_ctz(m) >> 1;
+                const float r = ((h >> (2 * p)) & 3u) == 1u ? this->rhet : this->rmis;
+                // `a` sites before the ratio, `b` after it (forward: a = p + 1, b = 7 - p; scan: a = 7 - p, b = p + 1,
+                // and the ratio goes BEFORE the site's own step)
+                switch (FWD ? p : 7 - p) {
+#define PHK_ONE(q)                                                                            \
+    case q:                                                                                   \
+        if (FWD) {                                                                            \
+            x = dense16(x, this->P[q]) * r;                                                   \
+            if (q < 7) x = dense16(x, this->P[q < 7 ? 6 - q : 0]);                            \
+        } else {                                                                              \
+            if (q > 0) x = dense16(x, this->P[q > 0 ? q - 1 : 0]);                            \
+            x = dense16(x * r, this->P[7 - q]);                                               \
+        }                                                                                     \
+        break;
+                    PHK_ONE(0) PHK_ONE(1) PHK_ONE(2) PHK_ONE(3) PHK_ONE(4) PHK_ONE(5) PHK_ONE(6)
+                    default:
+                    PHK_ONE(7)
+#undef PHK_ONE
+                }
+                return debt0 + 8 + 16;
+            }
+            // two or more het / missing sites: run by run
+            int debt = debt0;
+            if (FWD) {
+                uint32_t rem = h;
+                int left = 8;
+#pragma nounroll
+                do {
+                    const int tz = rem != 0u ? (__builtin_ctz(rem) >> 1) : 32;
+                    const bool stop = tz < left;  // the run ends in a het / missing site
+                    const int run = stop ? tz + 1 : left;
+                    x = hom_power<8>(x, run);
+                    if (stop) {
+                        x *= ((rem >> (2 * tz)) & 3u) == 1u ? this->rhet : this->rmis;
+                        debt += 16;
+                    }
+                    debt += run;
+                    rem >>= 2 * run;  // (run <= 8: at most 16 bits)
+                    left -= run;
+                    if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
+                } while (left > 0);
+            } else {
+                int left = 8;  // sites [0, left) are still to do; the next one is left - 1
+#pragma nounroll
+                do {
+                    const uint32_t top = (h >> (2 * (left - 1))) & 3u;
+                    if (top != 0u) {
+                        x *= top == 1u ? this->rhet : this->rmis;
+                        debt += 16;
+                    }
+                    const uint32_t below = h & ((1u << (2 * (left - 1))) - 1u);
+                    const int s = below != 0u ? (31 - __builtin_clz(below)) >> 1 : -1;  // next het / missing site to the left
+                    const int run = left - 1 - s;
+                    x = hom_power<8>(x, run);
+                    debt += run;
+                    left = s + 1;
+                    if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
+                } while (left > 0);
+            }
+            return debt;
+        } else {
+            return debt0;
+        }
+    }
+
+    // power-of-two rescale of a one-state-per-lane vector held in a scalar register per lane; returns the exponent removed
+    __device__ __forceinline__ int rescale1(float& x) const {
+        const float c = g.sum(x);
+        const int ex = frexp_exp_(c);
+        x *= ldexp_(1.0f, -ex);
+        return ex;
+    }
     // power-of-two rescale of a state vector on its own (the SCALE part of fwd_site / bt_site)
     __device__ __forceinline__ int rescale(V (&x)[NP]) const {
         const real c = total(x);
@@ -787,9 +883,6 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 #ifndef PHK_DENSE16
 #define PHK_DENSE16 1  // A/B: 0 = no M_h^16 step
 #endif
-#ifndef PHK_DENSE_RESCALE_SITES
-#define PHK_DENSE_RESCALE_SITES 64  // dense hom-run steps: rescale once this many hom sites have gone by without one (8: after every step)
-#endif
 #ifndef PHK_FWD_LEAN
 #define PHK_FWD_LEAN 1  // A/B: 0 = lean piece loops in the one-state-per-lane kernels only (1: in every forward kernel and beta scan)
 #endif
@@ -971,45 +1064,32 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         }
     };
     // One full block of a wave whose sequences share their observation row (uni): `rem` holds the block's codes as a
-    // SCALAR.  The block is cut into runs "hom^(n-1), then a het or missing site" (the last run may have no such end);
-    // a run is one dense M_h^n step plus, for its end, one multiply by emis1 / emis0 or 1 / emis0.  At 5 % hets + 1 %
-    // missing a mixed block is ~2 dense steps where it used to be one or two dense steps, two structured sites and two
-    // rescales.  Rescales: when the debt (1 per hom site, 16 per het / missing site) reaches PHK_DENSE_RESCALE_SITES,
-    // i.e. after at most 64 hom or 4 other sites as before.  Returns the exponent taken out of the block.
-    auto uni_block = [&](uint32_t rem) -> int {
+    // SCALAR.  A run "hom^(n-1), then a het or missing site" is one dense M_h^n step plus one multiply by emis1 / emis0
+    // or 1 / emis0 (Lane::half_step: straight-line code for the all-hom half and for a half with one such site).
+    // Rescales: when the debt (1 per hom site, 16 per het / missing site) reaches PHK_DENSE_RESCALE_SITES, i.e. after
+    // at most 64 hom or 4 other sites as before.  Returns the exponent taken out of the block.
+    auto uni_block = [&](const uint32_t rem) -> int {
         int dE = 0;
         if constexpr (DENSE) {
-            if (rem == 0u) {  // all hom: most blocks
-                a[0][0] = T == 16 ? dense16(a[0][0], lane.D16) : dense16(a[0][0], lane.P[7]);
-                hom_run += T;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    dE = lane.rescale(a);
-                    ex_min = dE < ex_min ? dE : ex_min;
+            float x = a[0][0];
+            auto resc = [&](float& y) -> int {
+                const int ex = lane.rescale1(y);
+                dE += ex;
+                ex_min = ex < ex_min ? ex : ex_min;
+                return 0;
+            };
+            if (T == 16 && __builtin_expect(rem == 0u, 1)) {
+                x = dense16(x, lane.D16);
+                hom_run += 16;
+            } else {
+                hom_run = lane.template half_step<true>(x, rem & 0xffffu, hom_run, resc);
+                if constexpr (T == 16) {
+                    if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
+                    hom_run = lane.template half_step<true>(x, rem >> 16, hom_run, resc);
                 }
-                return dE;
             }
-            int left = T;
-#pragma nounroll
-            do {
-                const int tz = rem != 0u ? (__builtin_ctz(rem) >> 1) : 32;
-                const bool stop = tz < left;  // the run ends in a het / missing site
-                const int run = stop ? tz + 1 : left;
-                a[0][0] = lane.template hom_power<T>(a[0][0], run);
-                if (stop) {
-                    a[0][0] *= ((rem >> (2 * tz)) & 3u) == 1u ? lane.rhet : lane.rmis;
-                    hom_run += 16;
-                }
-                hom_run += run;
-                rem = run < 16 ? rem >> (2 * run) : 0u;
-                left -= run;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    const int ex = lane.rescale(a);
-                    dE += ex;
-                    ex_min = ex < ex_min ? ex : ex_min;
-                }
-            } while (left > 0);
+            if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
+            a[0][0] = x;
         }
         return dE;
     };
@@ -1092,7 +1172,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 #endif
                           ck_u += ck_step;
                       }
-                      const int dE = uni_block((uint32_t)lo & (T == 16 ? 0xffffffffu : (1u << (2 * T)) - 1u));
+                      const int dE = uni_block((uint32_t)lo & (uint32_t)((uint64_t(1) << (2 * T)) - 1u));
                       E += dE;
                       if constexpr (CKPT) {
                           eb_u[sq_off] = (int16_t)dE;
@@ -1872,34 +1952,21 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     // left", one dense M_h^n step; the leading run of a word may start with a hom site.
     auto uni_word = [&](const uint32_t rem) {
         if constexpr (DENSE) {
-            if (rem == 0u) {  // all hom
-                beta[0][0] = dense16(beta[0][0], lane.D16);
+            float x = beta[0][0];
+            auto resc = [&](float& y) -> int {
+                F += lane.rescale1(y);
+                return 0;
+            };
+            if (__builtin_expect(rem == 0u, 1)) {  // all hom
+                x = dense16(x, lane.D16);
                 hom_run += 16;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    F += lane.rescale(beta);
-                }
-                return;
+            } else {
+                hom_run = lane.template half_step<false>(x, rem >> 16, hom_run, resc);
+                if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
+                hom_run = lane.template half_step<false>(x, rem & 0xffffu, hom_run, resc);
             }
-            int left = 16;  // sites [0, left) are still to do; the next one is left - 1
-#pragma nounroll
-            do {
-                const uint32_t top = (rem >> (2 * (left - 1))) & 3u;
-                if (top != 0u) {
-                    beta[0][0] *= top == 1u ? lane.rhet : lane.rmis;
-                    hom_run += 16;
-                }
-                const uint32_t below = rem & ((1u << (2 * (left - 1))) - 1u);
-                const int s = below != 0u ? (31 - __builtin_clz(below)) >> 1 : -1;  // next het / missing site to the left
-                const int run = left - 1 - s;
-                beta[0][0] = lane.template hom_power<16>(beta[0][0], run);
-                hom_run += run;
-                left = s + 1;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    F += lane.rescale(beta);
-                }
-            } while (left > 0);
+            if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
+            beta[0][0] = x;
         }
     };
     for (; w >= 0; --pc) {

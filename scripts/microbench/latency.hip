@@ -73,6 +73,53 @@ __global__ void k(int mode, int iters, float* out, long long* cyc, long long* wa
 #pragma unroll
             for (int u = 0; u < 4; ++u) x = rescale(dense16(x, d), E);
         }
+    } else if (mode == 5) {  // a loop whose body is one dependent add: cost of the taken back-edge
+#pragma nounroll
+        for (int i = 0; i < iters * 4; ++i) x = x + 1e-6f;
+    } else if (mode == 6) {  // ... with a skipped forward branch per iteration (two taken branches)
+#pragma nounroll
+        for (int i = 0; i < iters * 4; ++i) {
+            if (__builtin_amdgcn_readfirstlane(i) & 0x40000000) x = x * 0.5f;
+            x = x + 1e-6f;
+        }
+    } else if (mode == 7) {  // 16 independent v_fmac_f32_dpp row_newbcast (4 chains), no combine: the dense step's issue cost
+        float c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+            }
+        }
+        x = (c0 + c1) + (c2 + c3);
+    } else if (mode == 8) {  // 16 independent plain v_fmac_f32 (no DPP)
+        float c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile("v_fmac_f32 %0, %4, %5\n\tv_fmac_f32 %1, %4, %6\n\tv_fmac_f32 %2, %4, %7\n\tv_fmac_f32 %3, %4, %8"
+                             : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+            }
+        }
+        x = (c0 + c1) + (c2 + c3);
+    } else if (mode == 9) {  // 16 SALU adds in a dependent chain
+        int s = __builtin_amdgcn_readfirstlane(iters);
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) asm volatile("s_add_i32 %0, %0, 3" : "+s"(s));
+        }
+        E = s;
+    } else if (mode == 10) {  // dense16 + one checkpoint-like store per step
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                out[64 * ((4 * i + u) & 1023) + threadIdx.x] = x;
+                x = dense16(x, d);
+            }
+        }
     } else {
         for (int i = 0; i < iters; ++i) {
             const uint32_t w = words[i & 1023];
@@ -92,19 +139,23 @@ __global__ void k(int mode, int iters, float* out, long long* cyc, long long* wa
 
 int main() {
     float* out; long long *cyc, *wall; uint32_t* words;
-    hipMalloc(&out, 256); hipMalloc(&cyc, 8); hipMalloc(&wall, 8); hipMalloc(&words, 4096);
+    hipMalloc(&out, 64 * 1024 * 4 + 256); hipMalloc(&cyc, 8); hipMalloc(&wall, 8); hipMalloc(&words, 4096);
     hipMemset(words, 0, 4096);
-    const char* names[] = {"16 dependent v_fma_f32", "16 dependent (mul + dpp add)", "4 x dense16", "4 x (dense16 + rescale)", "word load + 4 x (vote + dense16 + rescale)"};
-    const int per[] = {16, 16, 4, 4, 4};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[] = {"16 dependent v_fma_f32", "16 dependent (mul + dpp add)", "4 x dense16", "4 x (dense16 + rescale)", "word load + 4 x (vote + dense16 + rescale)",
+                           "loop: 1 add + taken back-edge", "loop: 1 add + skipped forward branch + back-edge", "16 v_fmac_f32_dpp row_newbcast, 4 chains",
+                           "16 v_fmac_f32, 4 chains", "16 dependent s_add_i32", "4 x (store + dense16)"};
+    const int per[] = {16, 16, 4, 4, 4, 4, 4, 1, 1, 1, 4};
+    const int order[] = {0, 1, 2, 3, 11, 5, 6, 7, 8, 9, 10};
+    for (int mi = 0; mi < 11; ++mi) {
+        const int mode = order[mi];
         for (int rep = 0; rep < 2; ++rep) {
             const int iters = 20000;
             hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, mode, iters, out, cyc, wall, words);
             hipDeviceSynchronize();
             long long c, w;
             hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&w, wall, 8, hipMemcpyDeviceToHost);
-            if (rep) printf("%-44s: %7.1f cycles per step (%lld cycles, %.1f us wall, shader clock %.0f MHz)\n", names[mode],
-                            (double)c / iters / per[mode], c, w / 100.0, c / (w / 100.0));
+            if (rep) printf("%-52s: %7.1f cycles per step (%lld cycles, %.1f us wall, shader clock %.0f MHz)\n", names[mode == 11 ? 4 : mode],
+                            (double)c / iters / per[mode == 11 ? 4 : mode], c, w / 100.0, c / (w / 100.0));
         }
     }
     return 0;

@@ -215,7 +215,7 @@ def test_phk_log_prior_against_numpy_oracle(P, alpha, beta):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,D", [(1, 4), (2, 3), (7, 5), (20, 18), (33, 18)])
+@pytest.mark.parametrize("B,D", [(1, 4), (2, 3), (7, 5), (20, 18), (33, 18), (300, 18), (500, 18), (1000, 18)])
 def test_phk_svgd_step_against_loop_oracle(B, D):
     """``phk_svgd_step`` (three launches: functional gradient + AMSGrad, pairwise distances, median) against the
     loop-form restatement of blackjax.svgd + optax.amsgrad in ``oracle/svgd_numpy.py``, over consecutive steps."""
@@ -226,8 +226,8 @@ def test_phk_svgd_step_against_loop_oracle(B, D):
     x = torch.tensor(X, device="cuda")
     mu, nu, nmax = (torch.zeros_like(x) for _ in range(3))
     h = torch.ones(1, dtype=torch.float64, device="cuda")
-    ws = torch.empty(max(B * (B - 1) // 2, 1), dtype=torch.float64, device="cuda")
-    for it in range(4):
+    ws = torch.empty(int(lib.phk_svgd_workspace_doubles(B)), dtype=torch.float64, device="cuda")
+    for it in range(4 if B <= 100 else 2):  # (the loop-form oracle is O(B^2 D) in pure Python)
         G = rng.normal(size=(B, D)) * (1 + it)
         g = torch.tensor(G, device="cuda")
         x_out = torch.empty_like(x)
@@ -246,12 +246,16 @@ def test_phk_svgd_step_against_loop_oracle(B, D):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,kind", [(2, "normal"), (3, "normal"), (4, "normal"), (100, "normal"), (101, "normal"),
-                                    (250, "normal"), (250, "lattice"), (120, "copies"), (256, "lattice")])
+                                    (250, "normal"), (250, "lattice"), (120, "copies"), (256, "lattice"),
+                                    (257, "normal"), (500, "normal"), (501, "normal"), (500, "lattice"), (500, "copies"),
+                                    (500, "same"), (1000, "normal"), (2000, "normal"), (4096, "normal"), (3000, "lattice")])
 def test_median_select_of_the_svgd_step(B, kind):
     """The length scale the SVGD step leaves behind = median(pairwise distances)^2 / log B (the median heuristic of
-    blackjax 1.2.5, update_median_heuristic), from the single-workgroup bucket select: odd and even numbers of
-    distances, populations up to the in-kernel limit, and inputs whose distances take a handful of values only
-    (lattice points / repeated particles: buckets of thousands of equal keys, the narrowing path of the select)."""
+    blackjax 1.2.5, update_median_heuristic), from the bucket select -- one workgroup up to 256 particles, the whole
+    chip beyond (the reference's default population is 500, mcmc.py:193; the limit is 4,096 = 8.4 million distances):
+    odd and even numbers of distances, and inputs whose distances take a handful of values only (lattice points /
+    repeated / identical particles: buckets of thousands of equal keys, the narrowing path of the select).  Against
+    numpy.median of scipy's pdist, not the product's torch definition."""
     from scipy.spatial.distance import pdist
 
     from phlash_amd import svgd
@@ -261,9 +265,11 @@ def test_median_select_of_the_svgd_step(B, kind):
         X = rng.normal(size=(B, 18))
     elif kind == "lattice":
         X = rng.integers(0, 2, size=(B, 18)).astype(np.float64)
+    elif kind == "same":  # all particles identical: every distance 0 (the select's min == max exit)
+        X = np.repeat(rng.normal(size=(1, 18)), B, axis=0)
     else:  # five distinct particles, repeated
         X = rng.normal(size=(5, 18))[rng.integers(0, 5, size=B)]
-    assert B * (B - 1) // 2 <= svgd._MEDIAN_IN_KERNEL
+    # up to 256 particles one workgroup selects; beyond, the chip-wide select (no sort anywhere: svgd.step_hip)
     x = torch.tensor(X, device="cuda")
     st = svgd.init(x)
     new = svgd.step_hip(st, torch.zeros_like(x), 0.0)  # lr = 0: the particles stay where they are
@@ -381,3 +387,30 @@ def test_phk_chain_rule_against_numpy(K, extra):
     scale = np.abs(want_g[ok]).max(-1, keepdims=True)
     assert float((np.abs(got_g[ok] - want_g[ok]) / scale).max()) < 1e-13
     assert got_lp[4] == -np.inf and (got_g[4] == 0).all()
+
+
+@pytest.mark.gpu
+def test_svgd_step_beyond_the_hip_limits_equals_the_loop_oracle():
+    """``svgd.step`` takes the torch definition on the GPU where the HIP kernels do not reach (more than 72 coordinates
+    or more than 4,096 particles): here D = 80, against ``oracle/svgd_numpy.py`` over consecutive steps (the
+    particle limit is exercised through the same branch; a loop-form oracle at 4,097 particles would take hours)."""
+    from phlash_amd import svgd
+
+    B, D = 9, 80
+    rng = np.random.default_rng(80)
+    X = rng.normal(size=(B, D))
+    st, ref = svgd.init(torch.tensor(X, device="cuda")), osv.State(X)
+    called = []
+    orig = svgd.step_hip
+    svgd.step_hip = lambda *a, **k: called.append(1) or orig(*a, **k)
+    try:
+        for it in range(3):
+            G = rng.normal(size=(B, D)) * (1 + it)
+            st = svgd.step(st, torch.tensor(G, device="cuda"), 0.1)
+            ref = osv.step(ref, G, 0.1)
+            np.testing.assert_allclose(st.particles.cpu().numpy(), ref.particles, rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(float(st.length_scale), ref.length_scale, rtol=1e-11)
+    finally:
+        svgd.step_hip = orig
+    assert not called  # the HIP path was not taken
+    assert svgd.step(svgd.init(torch.zeros((4097, 3), dtype=torch.float64, device="cuda")), torch.zeros((4097, 3), dtype=torch.float64, device="cuda"), 0.1).particles.shape == (4097, 3)
