@@ -241,7 +241,7 @@ hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, in
 #endif
 #if PHK_BWD_PART
 hipError_t PHK_CAT(launch_finalize_, PHK_SUFFIX)(const KArgs& a, int units, hipStream_t st) {
-    const int64_t n = ((a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin) * KK;
+    const int64_t n = ((a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin) * 7 * KK;
     hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, KK, units);
     return hipGetLastError();
 }

@@ -353,23 +353,43 @@ constexpr int CR_MAXJ = 7 * PM_MAXK, CR_MAXD = PM_MAXK + 3;
 
 __global__ __launch_bounds__(128) void chain_rule_kernel(CRArgs A) {
     __shared__ double G[CR_MAXJ];
+    __shared__ double part[8][CR_MAXD];  // partial sums of J^T G over eight slices of j, added in slice order
     __shared__ double pg[CR_MAXD];
     __shared__ double pv;
     const int64_t b = blockIdx.x;
     const int t = threadIdx.x, J = A.J, D = A.D;
     const double* row = A.buf + b * (1 + J);
     for (int j = t; j < J; j += 128) G[j] = row[1 + j];
-    if (t == 127) pv = log_prior_one(A.P, A.alpha, A.beta, A.x + b * D, pg);  // (a lane that holds no coordinate)
+    if (t == 127) pv = log_prior_one(A.P, A.alpha, A.beta, A.x + b * D, pg);  // (a lane that holds no coordinate while D <= 67 < 120)
     __syncthreads();
-    double acc = 0.0;
-    if (t < D) {
+    // thread (slice, d): consecutive d read consecutive addresses of a Jacobian row; a slice takes a contiguous range of
+    // rows j, and the slices are added in slice order: the order of the sum is fixed (bit-reproducible)
+    const int lanes = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
+    const int slices = 128 / lanes;  // 8, 4 or 2 (D <= 67: at least 2... D > 64 falls back to one slice of 128 lanes)
+    const int sl = t / lanes, d = t - sl * lanes;
+    if (D <= 64) {
+        const int per = (J + slices - 1) / slices;
+        const int j0 = sl * per, j1 = j0 + per < J ? j0 + per : J;
+        double acc = 0.0;
+        if (d < D) {
+            const double* jc = A.jac + b * (int64_t)J * D + d;
+            for (int j = j0; j < j1; ++j) acc = fma(G[j], jc[(int64_t)j * D], acc);
+            part[sl][d] = acc;
+        }
+    } else if (t < D) {
+        double acc = 0.0;
         const double* jc = A.jac + b * (int64_t)J * D + t;
         for (int j = 0; j < J; ++j) acc = fma(G[j], jc[(int64_t)j * D], acc);
+        part[0][t] = acc;
     }
+    __syncthreads();
     double lp = A.c_prior * pv + A.c_hmm * row[0];
     if (A.extra_val) lp += A.c_extra * A.extra_val[b];
     const bool fin = isfinite(lp);
     if (t < D) {
+        double acc = part[0][t];
+        if (D <= 64)
+            for (int q = 1; q < slices; ++q) acc += part[q][t];
         double gx = A.c_prior * pg[t] + A.c_hmm * acc;
         if (A.extra_grad) gx += A.c_extra * A.extra_grad[b * D + t];
         A.grad[b * D + t] = fin ? gx : 0.0;

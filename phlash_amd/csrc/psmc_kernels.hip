@@ -569,6 +569,11 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
                     n -= 8;
                 }
             }
+            if constexpr (NMAX <= 4) {
+                if (n == 4) return dense16(x, this->P[3]);
+                if (n & 2) return (n & 1) ? dense16(x, this->P[2]) : dense16(x, this->P[1]);
+                return dense16(x, this->P[0]);
+            }
             if (n == 8) return dense16(x, this->P[7]);
             if (n & 4) {
                 if (n & 2) return (n & 1) ? dense16(x, this->P[6]) : dense16(x, this->P[5]);
@@ -586,7 +591,8 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // every ~6.5 cycles whether or not it depends on the one before, a dense step is 94 cycles, a rescale 72, and a
     // TAKEN branch ~40 -- six instructions' worth.  So the shapes that matter get straight-line code behind ONE
     // dispatch: all hom (one dense step), and exactly one het / missing site at position p (two dense steps and a
-    // multiply, 8-way switch on p).  Anything else takes the run loop (a dispatch per run).
+    // multiply, 8-way switch on p).  Two or more such sites: the same by quarters of four sites, and run by run (a
+    // dispatch per run) only inside a quarter that holds two or more.
     // Forward form (FWD): sites 0 .. 7 in order, x <- x M_h^(p+1) .* ratio, then M_h^(7-p).
     // Beta-scan form: sites 7 .. 0, x <- M_h^(p+1) (ratio .* (M_h^(7-p) x)).
     // Returns the rescale debt of the half (1 per hom site, 16 per het / missing site); `resc(x)` is called after a run
@@ -623,43 +629,75 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
                 }
                 return debt0 + 8 + 16;
             }
-            // two or more het / missing sites: run by run
+            // two or more het / missing sites: by quarters of four sites -- all hom: M_h^4; one such site: 4-way
+            // dispatch; more: run by run (a dispatch per run)
             int debt = debt0;
-            if (FWD) {
-                uint32_t rem = h;
-                int left = 8;
 #pragma nounroll
-                do {
-                    const int tz = rem != 0u ? (__builtin_ctz(rem) >> 1) : 32;
-                    const bool stop = tz < left;  // the run ends in a het / missing site
-                    const int run = stop ? tz + 1 : left;
-                    x = hom_power<8>(x, run);
-                    if (stop) {
-                        x *= ((rem >> (2 * tz)) & 3u) == 1u ? this->rhet : this->rmis;
-                        debt += 16;
+            for (int qi = 0; qi < 2; ++qi) {
+                const uint32_t hq = (h >> (8 * (FWD ? qi : 1 - qi))) & 0xffu;
+                if (hq == 0u) {
+                    x = dense16(x, this->P[3]);
+                    debt += 4;
+                    continue;
+                }
+                const uint32_t mq = (hq | (hq >> 1)) & 0x55u;
+                if ((mq & (mq - 1u)) == 0u) {
+                    const int p = __builtin_ctz(mq) >> 1;
+                    const float r = ((hq >> (2 * p)) & 3u) == 1u ? this->rhet : this->rmis;
+                    switch (FWD ? p : 3 - p) {
+#define PHK_ONE4(q)                                                                           \
+    case q:                                                                                   \
+        if (FWD) {                                                                            \
+            x = dense16(x, this->P[q]) * r;                                                   \
+            if (q < 3) x = dense16(x, this->P[q < 3 ? 2 - q : 0]);                            \
+        } else {                                                                              \
+            if (q > 0) x = dense16(x, this->P[q > 0 ? q - 1 : 0]);                            \
+            x = dense16(x * r, this->P[3 - q]);                                               \
+        }                                                                                     \
+        break;
+                        PHK_ONE4(0) PHK_ONE4(1) PHK_ONE4(2)
+                        default:
+                        PHK_ONE4(3)
+#undef PHK_ONE4
                     }
-                    debt += run;
-                    rem >>= 2 * run;  // (run <= 8: at most 16 bits)
-                    left -= run;
-                    if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
-                } while (left > 0);
-            } else {
-                int left = 8;  // sites [0, left) are still to do; the next one is left - 1
+                    debt += 4 + 16;
+                } else if (FWD) {
+                    uint32_t rem = hq;
+                    int left = 4;
 #pragma nounroll
-                do {
-                    const uint32_t top = (h >> (2 * (left - 1))) & 3u;
-                    if (top != 0u) {
-                        x *= top == 1u ? this->rhet : this->rmis;
-                        debt += 16;
-                    }
-                    const uint32_t below = h & ((1u << (2 * (left - 1))) - 1u);
-                    const int s = below != 0u ? (31 - __builtin_clz(below)) >> 1 : -1;  // next het / missing site to the left
-                    const int run = left - 1 - s;
-                    x = hom_power<8>(x, run);
-                    debt += run;
-                    left = s + 1;
-                    if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
-                } while (left > 0);
+                    do {
+                        const int tz = rem != 0u ? (__builtin_ctz(rem) >> 1) : 32;
+                        const bool stop = tz < left;  // the run ends in a het / missing site
+                        const int run = stop ? tz + 1 : left;
+                        x = hom_power<4>(x, run);
+                        if (stop) {
+                            x *= ((rem >> (2 * tz)) & 3u) == 1u ? this->rhet : this->rmis;
+                            debt += 16;
+                        }
+                        debt += run;
+                        rem >>= 2 * run;
+                        left -= run;
+                        if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
+                    } while (left > 0);
+                } else {
+                    int left = 4;  // sites [0, left) of the quarter are still to do; the next one is left - 1
+#pragma nounroll
+                    do {
+                        const uint32_t top = (hq >> (2 * (left - 1))) & 3u;
+                        if (top != 0u) {
+                            x *= top == 1u ? this->rhet : this->rmis;
+                            debt += 16;
+                        }
+                        const uint32_t below = hq & ((1u << (2 * (left - 1))) - 1u);
+                        const int s = below != 0u ? (31 - __builtin_clz(below)) >> 1 : -1;  // next het / missing site to the left
+                        const int run = left - 1 - s;
+                        x = hom_power<4>(x, run);
+                        debt += run;
+                        left = s + 1;
+                        if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
+                    } while (left > 0);
+                }
+                if (debt >= PHK_DENSE_RESCALE_SITES) debt = resc(x);
             }
             return debt;
         } else {
@@ -2052,31 +2090,33 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
 // the result does not depend on the order in which the units ran) + bpi [B*S, K] -> grad [B*S, 7, K]
 template <typename real>
 __global__ void grad_finalize_kernel(KArgs A, int K, int units) {
+    // one thread per gradient entry (sequence, row, state): consecutive threads read consecutive addresses of every
+    // unit's slot (round 3 had one thread per (sequence, state) walking six rows: 115 us at the reference's production
+    // shape, 2,500 sequences x 196 units; the 188 MB of partial sums are what bounds this kernel)
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
     const int64_t nloc = seq_hi - A.seq_begin;
-    const int64_t idx = A.seq_begin * K + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= seq_hi * K) return;
-    const int64_t seq = idx / K;
-    const int k = (int)(idx - seq * K);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nloc * 7 * K) return;
+    const int64_t sl = idx / (7 * K);
+    const int rk = (int)(idx - sl * 7 * K);  // r * K + k
+    const int64_t seq = A.seq_begin + sl;
     const int64_t bb = seq / A.S, ss = seq - bb * A.S;
     const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
-    const double* ga = A.gacc + seq * 6 * K;
-    const real* pt = (const real*)A.part + (seq - A.seq_begin) * 6 * K + k;
-    double sum[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) sum[r] = ga[r * K + k];
-    for (int u = 1; u < units; ++u) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) sum[r] += (double)pt[r * K];
-        pt += nloc * 6 * K;
-    }
     real* out = (real*)A.grad + seq * 7 * K;
     const bool dl = A.grad_dlog != 0;
-    for (int r = 0; r < 4; ++r) out[r * K + k] = (real)(dl ? sum[r] * (double)p[r * K + k] : sum[r]);
-    out[4 * K + k] = (real)(dl ? sum[4] : sum[4] / (double)p[4 * K + k]);
-    out[5 * K + k] = (real)(dl ? sum[5] : sum[5] / (double)p[5 * K + k]);
-    const double bp = A.bpi[seq * K + k];
-    out[6 * K + k] = (real)(dl ? bp * (double)p[6 * K + k] : bp);
+    if (rk >= 6 * K) {  // the pi row
+        const double bp = A.bpi[seq * K + (rk - 6 * K)];
+        out[rk] = (real)(dl ? bp * (double)p[rk] : bp);
+        return;
+    }
+    double sum = A.gacc[seq * 6 * K + rk];
+    const real* pt = (const real*)A.part + sl * 6 * K + rk;
+    for (int u = 1; u < units; ++u) {
+        sum += (double)*pt;
+        pt += nloc * 6 * K;
+    }
+    if (rk < 4 * K) out[rk] = (real)(dl ? sum * (double)p[rk] : sum);
+    else out[rk] = (real)(dl ? sum : sum / (double)p[rk]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -87,6 +87,16 @@ class HipEngine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.load().phk_take_flags_async(self._h, dst.data_ptr(), ctypes.c_void_p(stream)))
 
+    def reduce_chunks(self, ll: torch.Tensor, g: torch.Tensor, buf: torch.Tensor):
+        """Outputs of ``run`` (ll [B, S] float64, g [B, S, 7, K] in the handle's float type) -> ``buf`` [B + 1, 1 + 7K]
+        float64: row b = [sum_s ll, sum_s g]; row B = this handle's flags as by ``take_flags_async`` (the device word
+        is cleared).  One launch, stream-ordered (``phk_reduce_chunks``)."""
+        B, S = ll.shape
+        assert g.is_contiguous() and ll.is_contiguous() and g.shape == (B, S, 7, self.K) and g.dtype == self.dtype
+        assert buf.is_contiguous() and buf.dtype == torch.float64 and buf.shape == (B + 1, 1 + 7 * self.K)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.load().phk_reduce_chunks(self._h, ll.data_ptr(), g.data_ptr(), B, S, buf.data_ptr(), ctypes.c_void_p(stream)))
+
     def set_deterministic(self, on: bool):
         _lib.check(_lib.load().phk_set_deterministic(self._h, int(bool(on))))
 

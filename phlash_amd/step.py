@@ -37,6 +37,25 @@ def fusable(template: MCMCParams, kern) -> bool:
     return eng is not None and eng.K_user == eng.K == get_pattern(template.pattern).M
 
 
+def particle_params(template: MCMCParams, x: torch.Tensor, double_precision: bool):
+    """x [B, D] float64 on the GPU -> (params [B, 1, 7, K] float64, Jacobian [B, 7K, D] float64, the block in the
+    kernels' float type [B, 1, 7, K] -- the float64 tensor itself for float64 kernels), one launch."""
+    dev = x.device
+    B, D = x.shape
+    pat = get_pattern(template.pattern)
+    K, P = pat.M, len(pat)
+    assert D == P + 3
+    epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
+    params = torch.empty((B, 1, 7, K), dtype=F64, device=dev)
+    jac = torch.empty((B, 7 * K, D), dtype=F64, device=dev)
+    p32 = None if double_precision else torch.empty((B, 1, 7, K), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().phk_param_map_rounded(
+        dev.index, K, P, epoch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), float(template.theta), x.data_ptr(), B,
+        params.data_ptr(), jac.data_ptr(), p32.data_ptr() if p32 is not None else None,
+        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return params, jac, (params if p32 is None else p32)
+
+
 def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_inds, afs=None, afs_transform=None,
                          reduce: bool = True):
     """(logp [B], d logp / d x [B, D]) for particles ``x`` [B, D] on the kernel's GPU.
@@ -52,22 +71,16 @@ def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_i
     pat = get_pattern(template.pattern)
     K, P = pat.M, len(pat)
     assert D == P + 3 and fusable(template, kern)
-    epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    params = torch.empty((B, 1, 7, K), dtype=F64, device=dev)
-    jac = torch.empty((B, 7 * K, D), dtype=F64, device=dev)
-    p32 = None if eng.double_precision else torch.empty((B, 1, 7, K), dtype=torch.float32, device=dev)
-    _lib.check(lib.phk_param_map_rounded(dev.index, K, P, epoch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                         float(template.theta), x.data_ptr(), B, params.data_ptr(), jac.data_ptr(),
-                                         p32.data_ptr() if p32 is not None else None, stream))
+    _params, jac, p_kernel = particle_params(template, x, eng.double_precision)
     if isinstance(local_inds, torch.Tensor):
         inds = local_inds.to(device=dev, dtype=torch.int64)
     else:
         inds = kern._inds_tensor(local_inds)
     buf = torch.empty((B + 1, 1 + 7 * K), dtype=F64, device=dev)
     if inds.numel():
-        ll, g = eng.run(params if p32 is None else p32, inds, warmup=kern.overlap, grad=True, dlog=False)
-        _lib.check(lib.phk_reduce_chunks(eng._h, ll.data_ptr(), g.data_ptr(), B, inds.numel(), buf.data_ptr(), stream))
+        ll, g = eng.run(p_kernel, inds, warmup=kern.overlap, grad=True, dlog=False)
+        eng.reduce_chunks(ll, g, buf)  # sums over the minibatch; row B: this evaluation's flags (the device word is cleared)
     else:  # a rank without a share of this minibatch contributes zeros (and its flags)
         buf.zero_()
         eng.take_flags_async(buf[B, :2])

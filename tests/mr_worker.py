@@ -35,7 +35,8 @@ def contigs(scenario):
     for i in range(8):  # one chunk row per contig: chunk_size 600 + overlap 50
         if scenario == "real_flag":
             het = np.zeros(650, dtype=np.int8)
-            het[60::24] = 1  # isolated hets only: at most one per rescale group of 4 sites
+            het[60::80] = 1  # isolated hets only: at most one between two rescales (the scalar-code path of the
+            # one-state-per-lane kernels rescales after 64 "debt" units: 1 per hom site, 16 per het)
             if i % 2 == 1:
                 het[304:312] = 1  # a run: a whole group of hets -> mass 1e-44 between two rescales
         else:
@@ -69,6 +70,18 @@ def main():
         handed.append(dst.clone())
 
     HipEngine.take_flags_async = take
+    # ... the fused step (phlash_amd/step.py) hands the flags over inside phk_reduce_chunks: row B of its buffer
+    orig_reduce = HipEngine.reduce_chunks
+
+    def reduce(self, ll, g, buf):
+        orig_reduce(self, ll, g, buf)
+        dst = buf[ll.shape[0], :2]
+        if scenario == "fake_flag" and rank == world - 1 and not state["faked"]:
+            state["faked"] = True
+            dst[0] = 1.0
+        handed.append(dst.clone())
+
+    HipEngine.reduce_chunks = reduce
     nrm_calls = []
     orig_nrm = HipEngine.set_rescale_interval
 
@@ -87,6 +100,19 @@ def main():
             return PSMCParams(b=pp.b, d=pp.d, u=pp.u, v=pp.v, emis0=1.0 - tiny, emis1=tiny, pi=pp.pi)
 
         mcmc.particles_to_psmc = extreme
+        # ... and the fused step's parameter map
+        import phlash_amd.step as fstep
+
+        orig_pp = fstep.particle_params
+
+        def extreme_blocks(template, x, double_precision):
+            params, jac, pk = orig_pp(template, x, double_precision)
+            for t in {id(params): params, id(pk): pk}.values():
+                t[:, :, 4, :] = 1.0 - 1e-11
+                t[:, :, 5, :] = 1e-11
+            return params, jac, pk
+
+        fstep.particle_params = extreme_blocks
 
     held_out = contigs("plain")[3] if scenario == "plain" else None
     try:

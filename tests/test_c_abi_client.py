@@ -67,5 +67,6 @@ def test_c_client_reproduces_reference_captured_vectors(tmp_path, dbl):
             dlog[int(t[1]), int(t[2]), int(t[3]), int(t[4])] = float(t[5])
     np.testing.assert_allclose(ll, G["ll_particles_f64_seed0"], rtol=1e-11 if dbl else 1e-5)
     ref = G["dlog_particles_f64_seed0"]
-    scale = np.maximum(np.abs(ref).max(-1, keepdims=True), 1e-300)
-    assert (np.abs(dlog - ref) / scale).max() < (2e-8 if dbl else 2e-3)  # dlog printed with 9 digits
+    from parity_bars import check, rowscaled
+
+    check(f"c_abi_client.{'f64' if dbl else 'f32'}", rowscaled(dlog, ref))  # (float64: dlog printed with 9 digits)

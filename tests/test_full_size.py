@@ -76,6 +76,19 @@ def _setup(K, B, S, L, W, dbl, seed=0):
     return data, P, eng
 
 
+
+def _ll_agree(name, a, b, dbl, rtol64):
+    """Two evaluations of the same log-likelihoods by different kernel variants / plans: float64 to ``rtol64``; float32
+    as the largest absolute difference over the batch (|ll| is 2e3 .. 3e4 on these rows, a nearly-all-missing row
+    ~20: an absolute figure is the honest one), held against its measured-x5 bar in tests/parity_bars.py."""
+    from parity_bars import check
+
+    if dbl:
+        np.testing.assert_allclose(a.cpu(), b.cpu(), rtol=rtol64, atol=0)
+    else:
+        check(name, float((a.double() - b.double()).abs().max()))
+
+
 def test_cfg1_single_long_chunk():
     """cfg1: one 10 Mb chunk (100,000 sites), K = 16, 1 particle; f32 and f64 against the oracle."""
     data, P, e64 = _setup(16, 1, 1, 100_000, 0, True)
@@ -103,7 +116,7 @@ def test_cfg2_properties(dbl):
     # the gradient call and the forward-only call may run different forward variants (the tuner picks
     # per shape): float32 variants agree to ~1e-3 absolute on these 60,000-site rows -- 2e-7 of the
     # typical |ll|, but 4e-5 of a row that is nearly all missing (|ll| ~ 20)
-    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-12 if dbl else 1e-6, atol=0 if dbl else 2e-3)
+    _ll_agree("full_size.ll_grad_vs_nograd.f32", ll0, ll, dbl, 1e-12)
     # bounded oracle sample: 3 particles x 6 chunks at full length
     sub = [0, 7, 11]
     chunks = [0, 123, 250, 333, 498, 499]
@@ -113,7 +126,7 @@ def test_cfg2_properties(dbl):
         eng.set_variant(R, 8)
         eng.set_rescale_interval(nrm)
         ll2, g2 = eng.run(P, inds, W, grad=True)
-        np.testing.assert_allclose(ll2.cpu(), ll.cpu(), rtol=1e-11 if dbl else 2e-6, atol=0 if dbl else 2e-3)  # see above
+        _ll_agree("full_size.ll_variants.f32", ll2, ll, dbl, 1e-11)  # see above
         # rows b, d, u, v, e0, e1 against the row's own maximum (floor 1); the pi row in the form the
         # reference kernel returns, pi_i * d ll / d pi_i (gpu.py:303-313), whose natural scale is 1
         gs = g.double().abs().amax(-1, keepdim=True).clamp_min(1.0)
@@ -226,7 +239,7 @@ def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False):
     print(f"K={K} B={B} S={S}: plan {plan}")
     _oracle_sample(ll, g, P, data, parts, chunks, W, False, f"K={K} B={B} S={S} L={L}")
     ll0 = eng.run(P, inds, W, grad=False)
-    np.testing.assert_allclose(ll0.cpu(), ll.cpu(), rtol=1e-6, atol=2e-3)
+    _ll_agree("full_size.ll_grad_vs_nograd.f32", ll0, ll, False, 0)
     del g, ll0
     # W = 0 over the whole batch, theta * d ll / d theta: sum_i pi_i dll/dpi_i = 1, and the emission rows
     # add up to the number of observed sites (the posterior state marginals sum to 1 at every site)
@@ -237,7 +250,10 @@ def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False):
     e_pi = float((pi_sum - 1).abs().max())
     e_ga = float((gamma / n_obs - 1).abs().max())
     print(f"   W=0 identities: |sum pi dll/dpi - 1| {e_pi:.2e}, |sum gamma / n_obs - 1| {e_ga:.2e}")
-    assert e_pi < 2e-3 and e_ga < 2e-3
+    from parity_bars import check
+
+    check("full_size.identity_pi.f32", e_pi)
+    check("full_size.identity_gamma.f32", e_ga)
     return eng
 
 
@@ -340,9 +356,9 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     eng.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
     ll_s, g_s = eng.run(P, inds, W, grad=True)
     assert torch.isfinite(g).all()
-    np.testing.assert_allclose(ll.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
+    _ll_agree("full_size.ll_plans.f32", ll, ll_s, False, 0)
     sub, chunks = [0, 40, 65, 66, 99], [0, 267, 268, 499]  # sequence 32768 = particle 65, chunk 268
-    np.testing.assert_allclose(ll_d.cpu(), ll_s.cpu(), rtol=1e-6, atol=2e-3)
+    _ll_agree("full_size.ll_plans.f32", ll_d, ll_s, False, 0)
     for name, l_, gg in (("hybrid", ll, g), ("hybrid, dense scan", ll_d, g_d), ("static plan", ll_r, g_r), ("serial", ll_s, g_s)):
         _oracle_sample(l_, gg, P, data, sub, chunks, W, False, f"cfg2 full batch, {name}")
 

@@ -174,22 +174,22 @@ def test_fit_reads_flags_one_step_late_with_the_same_result(monkeypatch, flag_at
     rng = np.random.default_rng(2)
     contigs = [RawContig(het_matrix=(rng.uniform(size=(1, 9000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
                for _ in range(3)]
-    orig_take, orig_nrm = HipEngine.take_flags_async, HipEngine.set_rescale_interval
+    orig_reduce, orig_nrm = HipEngine.reduce_chunks, HipEngine.set_rescale_interval
     out = {}
     for lagged in (False, True):
         seen = {"n": 0, "nrm": []}
 
-        def take(self, dst, seen=seen):
-            orig_take(self, dst)
+        def take(self, ll, g, buf, seen=seen):  # (the fused step hands the flags over in row B of phk_reduce_chunks' buffer)
+            orig_reduce(self, ll, g, buf)
             if seen["n"] == flag_at:
-                dst[0] = 1.0
+                buf[ll.shape[0], 0] = 1.0
             seen["n"] += 1
 
         def set_nrm(self, nrm=0, seen=seen):
             seen["nrm"].append(int(nrm))
             orig_nrm(self, nrm)
 
-        monkeypatch.setattr(HipEngine, "take_flags_async", take)
+        monkeypatch.setattr(HipEngine, "reduce_chunks", take)
         monkeypatch.setattr(HipEngine, "set_rescale_interval", set_nrm)
         res = fit(contigs, key=11, niter=6, overlap=100, chunk_size=2900, num_particles=40, minibatch_size=3,
                   progress=False, deterministic=True, lagged_check=lagged)

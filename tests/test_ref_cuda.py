@@ -26,6 +26,9 @@ AR = np.arange(10)
 KS = (4, 8, 16, 32)
 
 
+from parity_bars import check  # noqa: E402
+
+
 def _rowscaled(a, ref):
     return (np.abs(a - ref) / np.maximum(np.abs(ref).max(-1, keepdims=True), 1e-300)).max()
 
@@ -111,7 +114,7 @@ def test_hip_matches_reference_captured_vectors(K, dbl):
         ll, g = _engine(K, missing, dbl).run(Pt, inds, 0, grad=True)
         np.testing.assert_allclose(ll.cpu().numpy()[0], G[f"ll_missing_f64_K{K}_seed{seed}"], rtol=1e-11 if dbl else 1e-5)
         dlog = g[0].double().cpu().numpy() * P
-        assert _rowscaled(dlog, G[f"dlog_missing_f64_K{K}_seed{seed}"]) < (1e-9 if dbl else 2e-3)
+        check(f"ref_cuda.captured_vectors.{'f64' if dbl else 'f32'}", _rowscaled(dlog, G[f"dlog_missing_f64_K{K}_seed{seed}"]))
 
 
 @pytest.mark.gpu
@@ -127,7 +130,7 @@ def test_hip_dlog_mode_and_blocks_match_reference(dbl):
         _, missing = conftest_inputs(seed)
         ll, dlog = _engine(16, missing, dbl).run(Pt, inds, 0, grad=True, dlog=True)
         np.testing.assert_allclose(ll.cpu().numpy(), G[f"ll_particles_f64_seed{seed}"], rtol=1e-11 if dbl else 1e-5)
-        assert _rowscaled(dlog.double().cpu().numpy(), G[f"dlog_particles_f64_seed{seed}"]) < (1e-9 if dbl else 2e-3)
+        check(f"ref_cuda.dlog_blocks.{'f64' if dbl else 'f32'}", _rowscaled(dlog.double().cpu().numpy(), G[f"dlog_particles_f64_seed{seed}"]))
 
 
 @pytest.mark.gpu
@@ -141,7 +144,7 @@ def test_hip_cfg1_matches_reference(dbl):
     ll, g = eng.run(torch.tensor(P[None, None], device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), 0, grad=True)
     rel = abs(float(ll[0, 0]) / float(G["ll_cfg1_f64"]) - 1)
     assert rel < (1e-11 if dbl else 1e-5), rel
-    assert _rowscaled(g[0, 0].double().cpu().numpy() * P, G["dlog_cfg1_f64"]) < (1e-9 if dbl else 2e-3)
+    check(f"ref_cuda.cfg1.{'f64' if dbl else 'f32'}", _rowscaled(g[0, 0].double().cpu().numpy() * P, G["dlog_cfg1_f64"]))
     # ... and the float32 HIP kernel is at least as close to the reference's float64 result as the
     # reference's own float32 kernel is
     if not dbl:
@@ -180,7 +183,7 @@ def test_hip_vs_live_reference_kernels_random_inputs(K):
             ll_h, dlog_h = _engine(K, data, dbl).run(
                 torch.tensor(PB, device="cuda"), torch.tensor(inds, device="cuda"), 0, grad=True, dlog=True)
             np.testing.assert_allclose(ll_h.cpu().numpy(), ll_r, rtol=1e-11 if dbl else 1e-5)
-            assert _rowscaled(dlog_h.double().cpu().numpy(), dlog_r) < (1e-9 if dbl else 2e-3)
+            check(f"ref_cuda.live_short.{'f64' if dbl else 'f32'}", _rowscaled(dlog_h.double().cpu().numpy(), dlog_r))
 
 
 @pytest.mark.gpu
@@ -227,4 +230,4 @@ def test_hip_vs_live_reference_kernels_at_cfg2_row_length(K):
             ll_h, dlog_h = eng.run(Pt, it, 0, grad=True, dlog=True)
             assert eng.get_plan()["segmented"] == seg
             np.testing.assert_allclose(ll_h.cpu().numpy(), ll_r, rtol=1e-11 if dbl else 1e-5)
-            assert _rowscaled(dlog_h.double().cpu().numpy(), dlog_r) < (1e-8 if dbl else 2e-3), (dbl, seg)
+            check(f"ref_cuda.live_cfg2_rows.{'f64' if dbl else 'f32'}", _rowscaled(dlog_h.double().cpu().numpy(), dlog_r))
