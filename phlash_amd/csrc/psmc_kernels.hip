@@ -809,7 +809,8 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
 struct SeqAux {      // written by the forward kernel, read by the backward kernel
     double inv_end;  // 1 / sum(alpha) after the last site (scaled state)
     int32_t e_end;   // exponent total E after the last site: true alpha_L = alpha * 2^E
-    int32_t eb_min;  // smallest exponent total of any checkpoint block of the sequence (<= 0)
+    int32_t eb_min;  // smallest exponent total of any checkpoint block of the sequence (<= 0).  REQUIRED of every producer
+                     // of checkpoints: bwd_kernel decides from it whether the wave may take its unscaled hot body
 };
 
 struct KArgs {
@@ -823,7 +824,7 @@ struct KArgs {
     int64_t pstride_s;       // 0: one block per particle, broadcast over chunks
     int64_t B, S;
     double* ll;              // [B*S]
-    void* ckpt;              // [nblk, B*S, K] real  (null: forward only)
+    void* ckpt;              // [nblk][K/4 pieces][B*S][4 states] real: Lane::ck_lane / ck_elem  (null: forward only)
     SeqAux* aux;             // [B*S]
     void* grad;              // [B*S, 7, K] real
     double* gacc;            // [B*S, 6, K] f64 partial sums (f32 kernels), zeroed before launch
@@ -876,6 +877,12 @@ __device__ __forceinline__ int64_t checked_row(const KArgs& A, int64_t ss) {
 // (NRM = 1, the reference's schedule), which is always safe.
 constexpr int RISK_EXP_F32 = -64;
 constexpr int RISK_EXP_F64 = -600;
+// The dense steps of the one-state-per-lane kernels defer their rescale over up to 64 hom sites (or 4 het / missing
+// sites): the exponent such a rescale removes is the decay of up to 80 sites, not of 4, and a harmless 1 bit per site
+// would trip the threshold above -- flipping the kernel object to per-site rescaling for good.  Those rescales are
+// held against this threshold instead: the total still sits 2^30 above the smallest normal float, and a state that far
+// below the total carries nothing.
+constexpr int RISK_EXP_DEFERRED_F32 = -96;
 // The backward kernel runs a whole checkpoint block unscaled in its hot body (PHK_SWEEP_V2: both passes of a block
 // start from the checkpoint and only the block's exponent TOTAL is applied, to beta, at the block's edge).  A block out
 // of which the forward kernel took more than this many binary orders takes the general body instead (it rescales as
@@ -990,6 +997,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 
     int E = 0;
     int ex_min = 0;  // smallest exponent any rescale of this sequence removed
+    int exd_min = 0;  // ... of the deferred rescales of the dense steps (own threshold: RISK_EXP_DEFERRED_F32)
     int hom_run = 0;  // dense kernels: rescale debt -- hom sites stepped over since the last rescale (uniform path: + 16 per het / missing site)
     int eb_min = 0;   // smallest exponent total of any checkpoint block
     double llW = 0.0;
@@ -1055,7 +1063,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                     hom_run = 0;
                     const int ex = lane.rescale(a);
                     E += ex;
-                    ex_min = ex < ex_min ? ex : ex_min;
+                    exd_min = ex < exd_min ? ex : exd_min;
                 }
                 return;
             }
@@ -1068,7 +1076,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                         hom_run = 0;
                         const int ex = lane.rescale(a);
                         E += ex;
-                        ex_min = ex < ex_min ? ex : ex_min;
+                        exd_min = ex < exd_min ? ex : exd_min;
                     }
                     continue;
                 }
@@ -1113,7 +1121,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             auto resc = [&](float& y) -> int {
                 const int ex = lane.rescale1(y);
                 dE += ex;
-                ex_min = ex < ex_min ? ex : ex_min;
+                exd_min = ex < exd_min ? ex : exd_min;
                 return 0;
             };
             if (T == 16 && __builtin_expect(rem == 0u, 1)) {
@@ -1338,7 +1346,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
-        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || !(cend > 0.0)))
+        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || exd_min < RISK_EXP_DEFERRED_F32 || !(cend > 0.0)))
         atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
@@ -1463,6 +1471,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #pragma unroll
             for (int i = 0; i < SPL; ++i) dot = fma_(ca[L::ck_elem(i, nseq)], L::get(beta, i), dot);
             dot = lane.g.sum(dot);
+            // (a seed whose product with the checkpoint has underflowed cannot be normalised: the same remedy as for
+            // the forward kernel's rescale interval -- raise the flag, the host re-evaluates with per-site rescaling)
+            if (!(dot > real(0)) && active && rank == 0 && A.risk != nullptr) atomicOr(A.risk, FLAG_UNDERFLOW);
             const V inv = splat<real>(dot > real(0) ? real(1) / dot : real(1));
 #pragma unroll
             for (int h = 0; h < NP; ++h) beta[h] = beta[h] * inv;
@@ -1905,6 +1916,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         uni = __all((int)ss == ss0 && lane.etab[0] > 0x1p-30f) != 0;
     }
     int F = 0;
+    int f_min = 0, fd_min = 0;  // dense kernel: smallest exponent removed by a per-group / a deferred rescale (flag: see fwd_kernel)
     int hom_run = 0;  // dense kernel: rescale debt (hom sites stepped over since the last rescale; uniform path: + 16 per het / missing site)
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
     const int nw = (int)((A.Ltot + 15) / 16);
@@ -1944,7 +1956,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                 hom_run += 16;
                 if (hom_run >= PHK_DENSE_RESCALE_SITES) {
                     hom_run = 0;
-                    F += lane.rescale(beta);
+                    const int ex = lane.rescale(beta);
+                    F += ex;
+                    fd_min = ex < fd_min ? ex : fd_min;
                 }
                 return;
             }
@@ -1955,7 +1969,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                     hom_run += 8;
                     if (hom_run >= PHK_DENSE_RESCALE_SITES) {
                         hom_run = 0;
-                        F += lane.rescale(beta);
+                        const int ex = lane.rescale(beta);
+                        F += ex;
+                        fd_min = ex < fd_min ? ex : fd_min;
                     }
                     continue;
                 }
@@ -1980,7 +1996,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                             }
                         }
                     }
-                    F += lane.rescale(beta);
+                    const int ex = lane.rescale(beta);
+                    F += ex;
+                    f_min = ex < f_min ? ex : f_min;
                 }
             }
         }
@@ -1992,7 +2010,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         if constexpr (DENSE) {
             float x = beta[0][0];
             auto resc = [&](float& y) -> int {
-                F += lane.rescale1(y);
+                const int ex = lane.rescale1(y);
+                F += ex;
+                fd_min = ex < fd_min ? ex : fd_min;
                 return 0;
             };
             if (__builtin_expect(rem == 0u, 1)) {  // all hom
@@ -2083,6 +2103,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         }
 
       }
+    }
+    if constexpr (DENSE) {  // the scan's own underflow flag (its seeds feed the segment sweep; see fwd_kernel for the thresholds)
+        if (active && rank == 0 && A.risk != nullptr && (f_min < RISK_EXP_F32 || fd_min < RISK_EXP_DEFERRED_F32)) atomicOr(A.risk, FLAG_UNDERFLOW);
     }
 }
 

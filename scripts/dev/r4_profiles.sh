@@ -1,0 +1,12 @@
+# On the GPU box: the round's rocprofv3 evidence for every shape BASELINE.md quotes (Next #7).
+set -u
+scripts/profile.sh r04_cfg2 full
+scripts/profile.sh r04_prod full --config prod --het-rate 0.05
+scripts/profile.sh r04_prod_het10 full --config prod --het-rate 0.10
+scripts/profile.sh r04_prod_sim trace --config prod
+scripts/profile.sh r04_cfg4 full --config cfg4
+scripts/profile.sh r04_cfg5 full --config cfg5
+scripts/profile.sh r04_cfg3 full --config cfg3
+PHK_DETERMINISTIC=1 scripts/trace_kernels.sh gpurun_out/r04_timeline_cfg2 > gpurun_out/r04_timeline_cfg2.txt 2>&1
+PHK_DETERMINISTIC=1 scripts/trace_kernels.sh gpurun_out/r04_timeline_prod --config prod --het-rate 0.05 > gpurun_out/r04_timeline_prod_het5.txt 2>&1
+tail -n 12 gpurun_out/r04_timeline_cfg2.txt gpurun_out/r04_timeline_prod_het5.txt
