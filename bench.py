@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
+    ap.add_argument("--pool-chunks", type=int, default=0, help="hold this many chunk rows and draw the step's --chunks rows from "
+                    "them at random (with replacement, as fit() draws its minibatch: mcmc.py:277) instead of using the same rows every step")
     ap.add_argument("--autograd-step", action="store_true", help="chain rule by torch autograd instead of the fused HIP tail (dev A/B)")
     ap.add_argument("--variant", default="", help="R:T override for the kernel variant (dev)")
     ap.add_argument("--nrm", type=int, default=0, help="rescale interval override (dev; 0 = library default)")
@@ -348,14 +350,15 @@ def main():
     else:  # every rank owns its own S chunks of a (world x S)-chunk genome set
         S_total = world * S
     # (rows are i.i.d. draws from the model, so "rank r's rows" is a seed; particles are shared)
+    S_rows = max(S, a.pool_chunks)  # rows held by the kernel object (a pool the step's S rows are drawn from, or exactly S)
     if a.het_rate is not None:  # i.i.d. rows (the reference's conftest generator, tests/conftest.py:19-21) + 1 % missing
         g = np.random.default_rng(1000 + rank)
-        data = (g.random((S, W + L), dtype=np.float32) < a.het_rate).astype(np.int8)
+        data = (g.random((S_rows, W + L), dtype=np.float32) < a.het_rate).astype(np.int8)
         data.flat[g.integers(0, data.size, size=int(0.01 * data.size))] = -1
         data[:, 0] = np.maximum(data[:, 0], 0)
         data_note = f"i.i.d. Bernoulli({a.het_rate:g}) hets + 1 % missing"
     else:
-        data = simulate_chunks(K, S, W + L, seed=1000 + rank, theta=a.theta, rho=a.theta)
+        data = simulate_chunks(K, S_rows, W + L, seed=1000 + rank, theta=a.theta, rho=a.theta)
         data_note = f"rows simulated from the default {K}-state HMM at theta = rho = {a.theta:g} per window + 1 % missing"
     n16 = (data.shape[1] // 16) * 16
     data_stats = {
@@ -376,6 +379,11 @@ def main():
         kern._eng.set_rescale_interval(a.nrm)
     kern._eng.set_profiling(True)
     inds = torch.arange(S, device=dev)
+    draws = None
+    if a.pool_chunks > S:  # every step its own S rows of the pool, drawn up front and resident on the device
+        gi = np.random.default_rng(7)
+        draws = torch.as_tensor(gi.integers(0, S_rows, size=(a.steps + a.warmup + 1, S)), device=dev)
+    step_no = [0]
     state = svgd.init(x0.to(dev))
     c1 = 1.0  # full pass: every one of the N_total chunks once -> weight N/S = 1 (mcmc.py:244)
     flags = torch.zeros(2, dtype=torch.float64, device=dev)  # kernel flags of all steps, summed on the device
@@ -385,6 +393,10 @@ def main():
     use_fused = not a.autograd_step and fused_step.fusable(template, kern)
 
     def one_step(state):
+        nonlocal inds
+        if draws is not None:
+            inds = draws[step_no[0] % draws.shape[0]]
+            step_no[0] += 1
         if use_fused:
             # what fit() runs: parameter map -> kernels -> chunk sums + flags -> (all-reduce) -> prior + chain rule,
             # a fixed sequence of HIP launches (phlash_amd/step.py), then the SVGD update
@@ -430,6 +442,7 @@ def main():
         state = one_step(state)  # no host synchronisation inside the timed loop
     barrier()
     elapsed = time.perf_counter() - t0
+    inds = torch.arange(S, device=dev)  # (the legs below evaluate the first S rows, whatever the steps drew)
     # HIP events recorded around the kernels on their launch stream, resolved once, after the loop
     fwd_ms, bwd_ms, _n = kern._eng.timing_totals()
     plan = kern._eng.get_plan()
@@ -513,6 +526,8 @@ def main():
                             f"K={K}, {B} SVGD particles; full inner step (param map, HIP fwd+bwd, "
                             f"all-reduce, chain rule, SVGD update)",
                 "name": a.config,
+                "minibatch": (f"{S} rows drawn at random from a pool of {S_rows} every step (as fit() draws its minibatch)"
+                              if draws is not None else f"the same {S} rows every step"),
                 **data_stats,
                 "K": K, "particles": B, "chunks_per_gpu": S, "chunks_total": S_total, "chunk_size": L, "overlap": W,
                 "scaling_note": ("strong scaling: the total number of chunk rows is fixed and sharded over the ranks"
@@ -552,6 +567,28 @@ def main():
                 },
             },
         }
+        # Which BASELINE.json config this line is, and what to hold a multi-GPU value against: the
+        # N = 1 rate of the same config and the per-rank step a rank of this world size was measured to take alone on
+        # one GPU (scripts/scaling_expectation.py -> profiles/scaling_expectation.json; static file, not collected here).
+        out["baseline_config"] = (f"{a.config}: " + ("strong scaling, the fixed total of chunk rows is sharded over the ranks"
+                                                     if a.strong else "weak scaling, every rank holds the config's per-GPU workload"))
+        exp_path = os.path.join(ROOT, "profiles", "scaling_expectation.json")
+        if os.path.exists(exp_path) and a.het_rate is None and not a.double:
+            try:
+                ex = json.load(open(exp_path))
+                tab = ex.get("bench_expectation", {}).get(a.config)
+                if tab:
+                    row = tab.get(f"N={world}") or {}
+                    out["scaling_expectation"] = {
+                        "n1_value": tab.get("N=1", {}).get("value"),
+                        "per_rank_ms_per_step_measured_alone": row.get("ms_per_step"),
+                        "expected_value_at_this_n": row.get("value"),
+                        "expected_speedup_over_n1": row.get("speedup"),
+                        "source": "profiles/scaling_expectation.json (one GPU running one rank's share; the all-reduce of "
+                                  "[B+1, 1+7K] f64 adds ~10-40 us per step)",
+                    }
+            except Exception:
+                pass
         if ranks_identical is not None:
             out["ranks_identical_after_timed_loop"] = ranks_identical
         if per_rank is not None:

@@ -252,6 +252,14 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
                 p.R = Rs;
                 p.T = 16;
             }
+            // ... unless the batch gives the 8-states-per-lane float32 sweep (beta-first body, block partly in LDS:
+            // the fewest instructions per site) a chip full of units: then that sweep on 8-site blocks, which is what
+            // the tuner picks at the reference's production shape (500 x 5 x 100,000: sweep 2.2 ms against 3.7 with
+            // R = 4, T = 16; profiles/r04_ab_experiments.txt)
+            if (h->K == 16 && !h->dbl && valid_Rs(h, 2) && nseq * units * 2 / 64 >= 2048) {
+                p.R = 2;
+                p.T = 8;
+            }
         }
         return p;
     }

@@ -247,6 +247,12 @@ __device__ __forceinline__ float dense16(float x, const float (&d)[16]) {
 #ifndef PHK_DENSE_RESCALE_SITES
 #define PHK_DENSE_RESCALE_SITES 64  // dense steps: rescale once the debt (1 per hom site, 16 per het / missing site of the scalar-code path) reaches this
 #endif
+// The het / missing ratios emis1 / emis0 and 1 / emis0 exist for the scalar-code path while emis0 is not absurdly small
+// (the reference clips emissions at 1e-20 = 2^-66): at 2^-64 the ratio is 2^64, a state with alpha >= 2^-62 of the
+// total keeps its het contribution exactly, and a smaller one carries nothing in float32.  (2^-30 in the first
+// version sent every wave holding a particle with theta x t_M > 21 to the wave-vote path -- one in a few hundred
+// particles of fit()'s initial population at 5 % hets, and the slowest wave sets the kernel's time: +20 %.)
+constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #ifndef PHK_DENSE_UNI
 #define PHK_DENSE_UNI 1  // A/B: 0 = waves with one observation row take the wave-vote path like any other
 #endif
@@ -992,7 +998,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     bool uni = false;
     if constexpr (DENSE && PHK_DENSE_UNI != 0) {
         const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && lane.etab[0] > 0x1p-30f) != 0;
+        uni = __all((int)ss == ss0 && lane.etab[0] > RATIO_MIN_EMIS0) != 0;
     }
 
     int E = 0;
@@ -1913,7 +1919,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     bool uni = false;  // the wave's sequences share their observation row and the emission ratios exist (see fwd_kernel)
     if constexpr (DENSE && PHK_DENSE_UNI_SCAN != 0) {
         const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && lane.etab[0] > 0x1p-30f) != 0;
+        uni = __all((int)ss == ss0 && lane.etab[0] > RATIO_MIN_EMIS0) != 0;
     }
     int F = 0;
     int f_min = 0, fd_min = 0;  // dense kernel: smallest exponent removed by a per-group / a deferred rescale (flag: see fwd_kernel)

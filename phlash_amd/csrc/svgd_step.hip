@@ -92,34 +92,42 @@ struct SelGlobal {
     int hist[2048];
 };
 
-// distances of the strict lower triangle, row-major: pair p <-> (i, j), i > j, p = i (i - 1) / 2 + j
+// distances of the strict lower triangle, row-major: pair p <-> (i, j), i > j, p = i (i - 1) / 2 + j.  One workgroup
+// per 16 x 16 tile of (i, j) with its 32 particles in LDS (round 3 had one thread per pair recover (i, j) from p
+// with a float64 square root and read 2 D strided doubles: 51 us at 500 particles).
 __global__ __launch_bounds__(256) void pair_dist_kernel(const double* __restrict__ x, int64_t B, int D, double* __restrict__ out,
                                                         SelGlobal* G) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = B * (B - 1) / 2;
+    __shared__ double xi[16][SV_MAXD + 1], xj[16][SV_MAXD + 1];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;  // (workgroup-uniform)
+    const int t = threadIdx.x, a = t >> 4, c = t & 15;
+    for (int e = t; e < 16 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        const int64_t gi = 16 * (int64_t)ti + r, gj = 16 * (int64_t)tj + r;
+        xi[r][d] = gi < B ? x[gi * D + d] : 0.0;
+        xj[r][d] = gj < B ? x[gj * D + d] : 0.0;
+    }
+    __syncthreads();
+    const int64_t i = 16 * (int64_t)ti + a, j = 16 * (int64_t)tj + c;
     unsigned long long key_mn = ~0ull, key_mx = 0ull;
-    if (p < n) {
-        int64_t i = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
-        while (i * (i - 1) / 2 > p) --i;
-        while ((i + 1) * i / 2 <= p) ++i;
-        const int64_t j = p - i * (i - 1) / 2;
+    if (i < B && j < i) {
         double d2 = 0.0;
         for (int d = 0; d < D; ++d) {
-            const double df = x[i * D + d] - x[j * D + d];
+            const double df = xi[a][d] - xj[c][d];
             d2 = fma(df, df, d2);
         }
         const double dist = sqrt(d2);
-        out[p] = dist;
+        out[i * (i - 1) / 2 + j] = dist;
         key_mn = key_mx = (unsigned long long)__double_as_longlong(dist);
     }
-    if (G == nullptr) return;  // (wave-uniform: a kernel argument)
-    // min / max over the workgroup: wave shuffles, then one atomic per wave
+    if (G == nullptr) return;  // (a kernel argument: uniform)
+    // min / max over the wave by shuffles, then one atomic each per wave
     for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long a = __shfl_xor(key_mn, off), b = __shfl_xor(key_mx, off);
-        key_mn = a < key_mn ? a : key_mn;
-        key_mx = b > key_mx ? b : key_mx;
+        const unsigned long long p = __shfl_xor(key_mn, off), q = __shfl_xor(key_mx, off);
+        key_mn = p < key_mn ? p : key_mn;
+        key_mx = q > key_mx ? q : key_mx;
     }
-    if ((threadIdx.x & 63) == 0 && key_mn != ~0ull) {
+    if ((t & 63) == 0 && key_mn != ~0ull) {
         atomicMin(&G->mn, key_mn);
         atomicMax(&G->mx, key_mx);
     }
@@ -451,7 +459,8 @@ hipError_t launch_svgd_step(const SVArgs& a, double* dist_ws, double* h_out, hip
     SelGlobal* G = chip ? (SelGlobal*)(dist_ws + 2 * n) : nullptr;
     if (chip) hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(256), 0, st, G);
     if (n > 0) {
-        hipLaunchKernelGGL(pair_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)a.x_out, a.B, a.D, dist_ws, G);
+        const unsigned tiles = (unsigned)((a.B + 15) / 16);
+        hipLaunchKernelGGL(pair_dist_kernel, dim3(tiles, tiles), dim3(256), 0, st, (const double*)a.x_out, a.B, a.D, dist_ws, G);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -315,7 +315,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                                                    reduce=False),
                 state.particles, kern=train_kern)
             return g
-        local = parallel.split_minibatch(inds, rank, size)
+        local = inds if isinstance(inds, torch.Tensor) else parallel.split_minibatch(inds, rank, size)
         if fused:
             return step.log_density_and_grad(template, state.particles, c_host, train_kern, local, afs, afs_transform)[1]
         xs = state.particles.detach().requires_grad_(True)
@@ -360,8 +360,23 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             state = step_checked(before, inds_)
         assert train_kern.also_value == 1.0, "particles went non-finite"
 
+    # The minibatches of all iterations, drawn up front in the order the loop used to draw them (one rng.choice per
+    # iteration, with replacement, the same for all particles: mcmc.py:277) and uploaded ONCE: a host array handed to
+    # the kernels every iteration is a pageable host-to-device copy on the compute stream, which waits for everything
+    # queued before it -- the host could never run ahead of the device, and the lagged flag check bought nothing
+    # (round 4: 0.65 ms of a 6.3 ms iteration at the reference's production shape).  Chunk mode: every rank keeps its
+    # own share of every minibatch (possibly empty) as a view into one device buffer.
+    draws = [rng.choice(N, size=(S,)) for _ in range(niter)]
+    shares = draws if by_particles else [parallel.split_minibatch(d, rank, size) for d in draws]
+    flat = np.concatenate([np.asarray(v, dtype=np.int64) for v in shares]) if niter else np.zeros(0, np.int64)
+    n_rows = N if by_particles else len(mine)
+    assert flat.size == 0 or (0 <= flat.min() and flat.max() < n_rows), "minibatch index outside this rank's rows"  # gpu.py:197-199
+    flat_dev = torch.as_tensor(flat, device=dev)
+    ends = np.cumsum([len(v) for v in shares])
+    dev_inds = [flat_dev[(ends[k - 1] if k else 0):ends[k]] for k in range(niter)]
+
     for i in it:
-        inds = rng.choice(N, size=(S,))  # with replacement, the same for all particles (mcmc.py:277)
+        inds = dev_inds[i]
         if not lag:
             state = step_checked(state, inds)
         else:

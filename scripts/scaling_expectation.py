@@ -84,8 +84,38 @@ def main():
         bl = -(-500 // n)
         res["prod_particle_mode_per_rank"][f"N={n}"] = dict(particles=bl, **bench("--config", "prod", "--particles", bl, "--het-rate", a.het_rate, *common))
     res["cfg2_weak_per_rank"] = bench(*common)
+    if not a.skip_cfg3:
+        res["cfg3_strong_per_rank"]["N=1"] = dict(chunks=5000, **bench("--config", "cfg3", *common))
     res["all_reduce_alone"] = allreduce_alone({"cfg2/cfg3 [B+1, 1+7K] B=100 K=16": (101, 113), "prod particle mode [B+1, 1+D] B=500 D=18": (501, 19),
                                                "cfg5 B=500 K=32": (501, 225)})
+    # the table bench.py quotes in its line (scaling_expectation): value = whole-job site.particle / s if every rank
+    # takes the per-rank step measured here plus the all-reduce
+    ar_ms = res["all_reduce_alone"]["cfg2/cfg3 [B+1, 1+7K] B=100 K=16"]["us_per_call_world1"] * 1e-3
+    exp = {}
+    w = res["cfg2_weak_per_rank"]
+    if "ms_per_step" in w:
+        work = 100 * 500 * 60000
+        exp["cfg2"] = {f"N={n}": {"ms_per_step": round(w["ms_per_step"] + (ar_ms if n > 1 else 0), 3),
+                                  "value": n * work / ((w["ms_per_step"] + (ar_ms if n > 1 else 0)) * 1e-3),
+                                  "speedup": round(n * w["ms_per_step"] / (w["ms_per_step"] + (ar_ms if n > 1 else 0)), 3)}
+                       for n in (1, 2, 4, 8)}
+    c3 = res.get("cfg3_strong_per_rank", {})
+    if "N=1" in c3 and "ms_per_step" in c3["N=1"]:
+        work = 100 * 5000 * 60000
+        t1 = c3["N=1"]["ms_per_step"]
+        exp["cfg3"] = {}
+        for n in (1, 2, 4, 8):
+            r = c3.get(f"N={n}", {})
+            if "ms_per_step" in r:
+                t = r["ms_per_step"] + (ar_ms if n > 1 else 0)
+                exp["cfg3"][f"N={n}"] = {"ms_per_step": round(t, 3), "value": work / (t * 1e-3), "speedup": round(t1 / t, 3)}
+    pm = res["prod_particle_mode_per_rank"]
+    if "ms_per_step" in pm.get("N=1", {}):
+        work = 500 * 5 * 100000
+        t1 = pm["N=1"]["ms_per_step"]
+        exp["prod"] = {f"N={n}": {"ms_per_step": pm[f"N={n}"]["ms_per_step"], "value": work / (pm[f"N={n}"]["ms_per_step"] * 1e-3),
+                                  "speedup": round(t1 / pm[f"N={n}"]["ms_per_step"], 3)} for n in (1, 2, 4, 8) if "ms_per_step" in pm.get(f"N={n}", {})}
+    res["bench_expectation"] = exp
     print(json.dumps(res, indent=1))
 
 
