@@ -45,7 +45,7 @@ static size_t lds_bytes(int R, int nt) {
 #if PHK_FWD_PART || PHK_LAT_PART
 template <int R, int T, int NRM>
 static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
-    const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
+    const int64_t nseq = launch_groups<real_t, KK, R>(a);  // (the one-state-per-lane layout pads every chunk's particles: map_group)
     const int spb = nt / R;  // sequences per workgroup
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
     const size_t lds = lds_bytes(R, nt);
@@ -101,7 +101,7 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
 #if PHK_BWD_PART || PHK_LAT_PART
 template <int R, int NRM>
 static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_t* fseg, int nt, hipStream_t st) {
-    const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
+    const int64_t nseq = launch_groups<real_t, KK, R>(a);
     const int spb = nt / R;
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
     hipLaunchKernelGGL((bscan_kernel<real_t, KK, R, NRM>), grid, block, lds_bytes(R, nt), st, a, seg_sites, bseg, fseg);

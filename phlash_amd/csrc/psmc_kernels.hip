@@ -943,6 +943,52 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 template <typename real, int K, int R>
 constexpr int scan_waves_per_simd() { return has_dense<real, K, R>() ? PHK_DENSE_WAVES : 1; }
 
+// Which sequence a lane group of the forward kernel / beta scan works on.  Sequences are independent and everything
+// stored is indexed by seq = b * S + s, so the assignment is free.  In the one-state-per-lane layout a range of whole
+// particles is taken chunk-major, every chunk's particles padded to a multiple of FOUR groups: the four sequences of a
+// wave then read the same observation row (scalar codes: Lane::half_step; wave votes that succeed as often as one
+// sequence alone would), whatever the particle count (round 3 mapped without the padding: with 250, 125 or 63
+// particles -- a rank's share in particle mode -- the waves straddling two chunks took the slow path and set the
+// kernel's time).  Padding groups repeat the chunk's last particle: same row, same parameters, hence the same bits
+// to the same addresses in the store-by-every-lane loops.
+struct SeqMap {
+    int64_t bb, ss, seq;
+    bool active;     // this group holds a sequence of its own
+    bool idle_wave;  // no group of this wave does: the wave must leave (see fwd_kernel)
+};
+template <typename real, int K, int R>
+__host__ __device__ inline int64_t launch_groups(const KArgs& A) {  // lane groups a launch needs (grid = this / groups per workgroup)
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+    if (has_dense<real, K, R>() && A.S > 0 && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {
+        const int64_t nb = (seq_hi - A.seq_begin) / A.S;
+        return A.S * ((nb + 3) & ~int64_t(3));
+    }
+    return seq_hi - A.seq_begin;
+}
+template <typename real, int K, int R>
+__device__ __forceinline__ SeqMap map_group(const KArgs& A) {
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;               // this group, within the launch
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R);  // the wave's first group
+    SeqMap m;
+    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
+        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, nbp = (nb + 3) & ~int64_t(3);
+        const int64_t sc = g / nbp, r = g - sc * nbp;
+        m.idle_wave = gw >= A.S * nbp;
+        m.active = sc < A.S && r < nb;
+        m.ss = sc < A.S ? sc : A.S - 1;
+        m.bb = b0 + ((sc < A.S && r < nb) ? r : nb - 1);
+    } else {
+        m.idle_wave = A.seq_begin + gw >= seq_hi;
+        m.active = A.seq_begin + g < seq_hi;
+        const int64_t lin = m.active ? A.seq_begin + g : seq_hi - 1;
+        m.bb = lin / A.S;
+        m.ss = lin - m.bb * A.S;
+    }
+    m.seq = m.bb * A.S + m.ss;
+    return m;
+}
+
 template <typename real, int K, int R, int T, int NRM, bool CKPT>
 __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void fwd_kernel(KArgs A) {
     using L = Lane<real, K, R>;
@@ -952,37 +998,21 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     static_assert(T % NRM == 0, "the rescale schedule must restart with every block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int64_t nseq = A.B * A.S;
-    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
-    const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
-    const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
     // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
-    // not run: lane groups without a sequence repeat the last sequence's work and, in the lean piece loops, its
+    // not run: lane groups without a sequence repeat another sequence's work and, in the lean piece loops, its
     // stores -- harmless inside a wave that also holds the real group (same wave votes, hence the same dense /
     // structured steps, the same rescales, the same bits to the same addresses), but a wave made of repeats only
     // votes among copies of ONE sequence, takes dense steps and rescales where the real group's wave does not, and its
     // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
     // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
     // checkpoints of one scaling and exponents of the other).
+    const SeqMap sm = map_group<real, K, R>(A);
 #ifndef PHK_KEEP_IDLE_WAVES  // (diagnostic builds define it to show that the regression test catches the race)
-    if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
+    if (sm.idle_wave) return;
 #endif
-    // Which sequence a lane group works on is free (sequences are independent; everything stored is
-    // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
-    // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
-    // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
-    // alone would (hom^4 per group instead of hom^16).
-    const int64_t lin = active ? gid : seq_hi - 1;
-    int64_t bb, ss;
-    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
-        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, l = lin - A.seq_begin;
-        ss = l / nb;
-        bb = b0 + (l - ss * nb);
-    } else {
-        bb = lin / A.S;
-        ss = lin - bb * A.S;
-    }
-    const int64_t seq = bb * A.S + ss;
+    const bool active = sm.active;
+    const int64_t bb = sm.bb, ss = sm.ss, seq = sm.seq;
 
     L lane;
     V a[NP];
@@ -991,9 +1021,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
     if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank);
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
-    // Do the four sequences of this wave read ONE observation row (true for every wave of a range of whole particles
-    // whose particle count is a multiple of four, e.g. the reference's 500), and are their hom emissions far enough
-    // from zero for the het / missing ratios to exist?  Then the codes are scalars and every run of sites is one
+    // Do the four sequences of this wave read ONE observation row (true for every wave of a range of whole particles:
+    // map_group), and are their hom emissions far enough from zero for the het / missing ratios to exist?  Then the codes are scalars and every run of sites is one
     // dense step (uni_block below).  Other waves keep the wave-vote path.
     bool uni = false;
     if constexpr (DENSE && PHK_DENSE_UNI != 0) {
@@ -1873,37 +1902,14 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     __builtin_amdgcn_s_setprio(PHK_BSCAN_PRIO);
 #endif
     const int64_t nseq = A.B * A.S;
-    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : nseq;
-    const int64_t gid = A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;
-    const bool active = gid < seq_hi;
     const int rank = threadIdx.x & (R - 1);
-    // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
-    // not run: lane groups without a sequence repeat the last sequence's work and, in the lean piece loops, its
-    // stores -- harmless inside a wave that also holds the real group (same wave votes, hence the same dense /
-    // structured steps, the same rescales, the same bits to the same addresses), but a wave made of repeats only
-    // votes among copies of ONE sequence, takes dense steps and rescales where the real group's wave does not, and its
-    // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
-    // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
-    // checkpoints of one scaling and exponents of the other).
-#ifndef PHK_KEEP_IDLE_WAVES  // (diagnostic builds define it to show that the regression test catches the race)
-    if (A.seq_begin + (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R) >= seq_hi) return;
+    // (idle waves leave, lane groups are mapped to sequences as in fwd_kernel: see map_group)
+    const SeqMap sm = map_group<real, K, R>(A);
+#ifndef PHK_KEEP_IDLE_WAVES
+    if (sm.idle_wave) return;
 #endif
-    // Which sequence a lane group works on is free (sequences are independent; everything stored is
-    // indexed by seq = b * S + s).  In the one-state-per-lane layout neighbouring groups take the
-    // SAME chunk for neighbouring particles: the four sequences of a wave then see the same
-    // observations and the wave vote for a dense hom-run step succeeds as often as one sequence
-    // alone would (hom^4 per group instead of hom^16).
-    const int64_t lin = active ? gid : seq_hi - 1;
-    int64_t bb, ss;
-    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
-        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, l = lin - A.seq_begin;
-        ss = l / nb;
-        bb = b0 + (l - ss * nb);
-    } else {
-        bb = lin / A.S;
-        ss = lin - bb * A.S;
-    }
-    const int64_t seq = bb * A.S + ss;
+    const bool active = sm.active;
+    const int64_t bb = sm.bb, ss = sm.ss, seq = sm.seq;
 
     L lane;
     V pi[NP], beta[NP];

@@ -10,3 +10,7 @@ scripts/profile.sh r04_cfg3 full --config cfg3
 PHK_DETERMINISTIC=1 scripts/trace_kernels.sh gpurun_out/r04_timeline_cfg2 > gpurun_out/r04_timeline_cfg2.txt 2>&1
 PHK_DETERMINISTIC=1 scripts/trace_kernels.sh gpurun_out/r04_timeline_prod --config prod --het-rate 0.05 > gpurun_out/r04_timeline_prod_het5.txt 2>&1
 tail -n 12 gpurun_out/r04_timeline_cfg2.txt gpurun_out/r04_timeline_prod_het5.txt
+python3 scripts/scaling_expectation.py > gpurun_out/r04_scaling_expectation.json 2> gpurun_out/r04_scaling_expectation.err
+scripts/round_lines.sh r04
+python3 scripts/fit_timing.py > gpurun_out/r04_fit_timing.txt 2>&1
+./scripts/microbench/latency > gpurun_out/r04_microbench_latency.txt 2>&1

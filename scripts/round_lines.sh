@@ -2,7 +2,7 @@
 # On the GPU box: the tracked bench lines of a round (one per BASELINE config + het-rate variants + float64 + the torchrun
 # form at world size 1), written to gpurun_out/lines_<tag>/ for copying into profiles/.
 #   scripts/round_lines.sh <tag>
-TAG=${1:-r03}; OUT=gpurun_out/lines_$TAG; mkdir -p $OUT
+TAG=${1:-r04}; OUT=gpurun_out/lines_$TAG; mkdir -p $OUT
 run() { name=$1; shift; python3 bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "$name FAILED (see $OUT/$name.err)"; }
 run bench_cfg2
 run bench_cfg1 --config cfg1 --cpu-seconds 5
