@@ -233,6 +233,10 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
     Plan p;
     p.T = h->force_T ? h->force_T : 8;
     p.R = h->force_R ? h->force_R : throughput_R(h, nseq, p.T, 1);
+    // K = 16 float32: never 16 states per lane in the sweep -- the beta-first body with its block partly in LDS exists
+    // for 8 states per lane only and is the fastest per site.particle however large the batch (the tuner picks it at
+    // 50,000 and at 500,000 sequences alike: cfg2, cfg3)
+    if (!h->force_R && h->K == 16 && !h->dbl && p.R == 1 && valid_Rb(h, 2)) p.R = 2;
     const int64_t units = n_units(h, 8, W);
     // small batch: even with the most lanes per sequence a serial sweep would not give every SIMD four
     // waves -- the sweep is then a chain of L dependent sites per wave on a mostly idle chip
