@@ -233,10 +233,11 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
     Plan p;
     p.T = h->force_T ? h->force_T : 8;
     p.R = h->force_R ? h->force_R : throughput_R(h, nseq, p.T, 1);
-    // K = 16 float32: never 16 states per lane in the sweep -- the beta-first body with its block partly in LDS exists
-    // for 8 states per lane only and is the fastest per site.particle however large the batch (the tuner picks it at
-    // 50,000 and at 500,000 sequences alike: cfg2, cfg3)
-    if (!h->force_R && h->K == 16 && !h->dbl && p.R == 1 && valid_Rb(h, 2)) p.R = 2;
+    // float32: never 16 states per lane in the sweep -- the beta-first body (block partly in LDS) exists for 8 states
+    // per lane and below and is the fastest per site.particle however large the batch (the tuner picks 8 per lane at
+    // 50,000 and at 500,000 sequences alike, cfg2 / cfg3, and at K = 32, cfg5; with 16 per lane the static plan ran
+    // cfg4 at 289 ms and cfg5 at 551 against the tuner's 169 and 371)
+    if (!h->force_R && !h->dbl && h->K / p.R == 16 && valid_Rb(h, 2 * p.R)) p.R *= 2;
     const int64_t units = n_units(h, 8, W);
     // small batch: even with the most lanes per sequence a serial sweep would not give every SIMD four
     // waves -- the sweep is then a chain of L dependent sites per wave on a mostly idle chip

@@ -1,11 +1,7 @@
-for lib in base latprio; do for ov in 0 25 50; do
-if [ $lib = base ]; then unset PHK_LIB; else export PHK_LIB=$PWD/phlash_amd/csrc/exp/libphk_$lib.so; fi
-PHK_EXP_OVERLAP=$ov PHK_DETERMINISTIC=1 python3 bench.py --config prod --het-rate 0.05 --no-cpu-baseline --steps 40 > /tmp/bo.json 2>/tmp/bo.err; python3 - /tmp/bo.json $ov $lib <<'PY'
+for c in cfg4 cfg5 cfg3 cfg2; do PHK_DETERMINISTIC=1 python3 bench.py --config $c --no-cpu-baseline > /tmp/s.json 2>/dev/null; python3 - /tmp/s.json $c <<'PY'
 import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']
-    print(sys.argv[3], "overlap %", sys.argv[2], round(d['ms_per_step'],3), round(k['forward'],3), round(k['backward'],3))
-except Exception as e:
-    print("overlap", sys.argv[2], "failed:", open('/tmp/bo.err').read()[-300:])
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']
+print("static", sys.argv[2], round(d['ms_per_step'],3), round(k['forward'],3), round(k['backward'],3), d['config']['kernel_variant'])
 PY
-done; done
+done
+timeout 600 python3 -m pytest tests/test_plans_and_modes.py tests/test_full_size.py -q -m gpu -k "deterministic or static or plan" 2>&1 | tail -3
