@@ -256,6 +256,9 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #ifndef PHK_DENSE_UNI
 #define PHK_DENSE_UNI 1  // A/B: 0 = waves with one observation row take the wave-vote path like any other
 #endif
+#ifndef PHK_UNI_SLOAD
+#define PHK_UNI_SLOAD 1  // A/B: 0 = such waves read their observation words by vector loads like the others
+#endif
 #ifndef PHK_DENSE_UNI_SCAN
 #define PHK_DENSE_UNI_SCAN PHK_DENSE_UNI  // ... the beta scan alone
 #endif
@@ -951,6 +954,18 @@ constexpr int scan_waves_per_simd() { return has_dense<real, K, R>() ? PHK_DENSE
 // particles -- a rank's share in particle mode -- the waves straddling two chunks took the slow path and set the
 // kernel's time).  Padding groups repeat the chunk's last particle: same row, same parameters, hence the same bits
 // to the same addresses in the store-by-every-lane loops.
+// Observation pieces of a wave-uniform row through the scalar data path: a pointer into the constant address space
+// whose value sits in SGPRs (readfirstlane), so that the compiler emits s_load_dwordx4 (lgkmcnt) instead of a vector
+// load (vmcnt, shared with the stores).  The packed rows are written by pack_kernel before any of these kernels starts.
+typedef uint32_t PieceWords __attribute__((ext_vector_type(4)));  // (a builtin vector: copyable out of another address space)
+typedef const PieceWords __attribute__((address_space(4)))* ScalarPieces;
+__device__ __forceinline__ ScalarPieces scalar_pieces(const uint4* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return (ScalarPieces)(((uint64_t)hi << 32) | lo);
+}
+
 struct SeqMap {
     int64_t bb, ss, seq;
     bool active;     // this group holds a sequence of its own
@@ -1031,8 +1046,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     }
 
     int E = 0;
-    int ex_min = 0;  // smallest exponent any rescale of this sequence removed
-    int exd_min = 0;  // ... of the deferred rescales of the dense steps (own threshold: RISK_EXP_DEFERRED_F32)
+    // smallest distance to its threshold of any exponent a rescale of this sequence removed: RISK_EXP_* for the
+    // rescales after NRM sites, RISK_EXP_DEFERRED_F32 for the deferred rescales of the dense steps.  ONE variable on
+    // purpose: with two, the compiler sinks the updates into one block behind a select of their ADDRESSES, both stay
+    // in scratch, and every scratch_load's s_waitcnt vmcnt(0) also waits for the observation piece requested ahead
+    // (round 4: 35-42 % of the one-state-per-lane kernels' wave cycles went there)
+    constexpr int RISK_EXP = sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64;
+    int ex_slack = 1 << 20;
     int hom_run = 0;  // dense kernels: rescale debt -- hom sites stepped over since the last rescale (uniform path: + 16 per het / missing site)
     int eb_min = 0;   // smallest exponent total of any checkpoint block
     double llW = 0.0;
@@ -1098,7 +1118,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                     hom_run = 0;
                     const int ex = lane.rescale(a);
                     E += ex;
-                    exd_min = ex < exd_min ? ex : exd_min;
+                    ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
                 }
                 return;
             }
@@ -1111,7 +1131,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                         hom_run = 0;
                         const int ex = lane.rescale(a);
                         E += ex;
-                        exd_min = ex < exd_min ? ex : exd_min;
+                        ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
                     }
                     continue;
                 }
@@ -1139,7 +1159,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                     }
                     const int ex = lane.rescale(a);
                     E += ex;
-                    ex_min = ex < ex_min ? ex : ex_min;
+                    ex_slack = min(ex_slack, ex - RISK_EXP);
                 }
             }
         }
@@ -1156,7 +1176,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             auto resc = [&](float& y) -> int {
                 const int ex = lane.rescale1(y);
                 dE += ex;
-                exd_min = ex < exd_min ? ex : exd_min;
+                ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
                 return 0;
             };
             if (T == 16 && __builtin_expect(rem == 0u, 1)) {
@@ -1186,7 +1206,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             real sc;
             const int ex = lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
             E += ex;
-            if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
+            if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
             if (i + 1 < T) {
 #pragma unroll
                 for (int h = 0; h < NP; ++h) ec[h] = en[h];
@@ -1204,11 +1224,86 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // piece's words rotated through one register, wave-uniform store bases with 32-bit lane offsets, and
     // stores by every lane (lanes past the last sequence repeat its work bit for bit: same value, same address).
     constexpr bool LEAN = PPB == 1 && (DENSE ? PHK_DENSE_LEAN != 0 : (PHK_FWD_LEAN != 0 && PHK_EMIS_AHEAD < 2));
-    const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K < (int64_t(1) << 31);
-    const unsigned ck_off = (unsigned)L::ck_lane(nseq, seq, rank), sq_off = (unsigned)seq;
-    const unsigned ck_piece = (unsigned)(nseq * 4);  // distance between the pieces of one sequence
+    // (lane offsets of the lean stores are 32-bit BYTE offsets beside a wave-uniform base: the store then takes the
+    // base from SGPRs -- global_store ... v_off, v_data, s[base] -- and costs no address arithmetic per block)
+    const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K * (int64_t)sizeof(real) < (int64_t(1) << 31);
+    unsigned ck_off = (unsigned)L::ck_lane(nseq, seq, rank) * (unsigned)sizeof(real), sq_off = (unsigned)seq * 2u;  // bytes
+    const unsigned ck_piece = (unsigned)(nseq * 4) * (unsigned)sizeof(real);  // distance between the pieces of one sequence (bytes)
     int blk = 0;
+    // one lean piece (64 sites, full blocks, no warm-up boundary) of a wave whose sequences share their observation
+    // row: the piece's codes as two scalar 64-bit words, shifted down one block at a time
+    int64_t ck_step_b = ck_step * (int64_t)sizeof(real), eb_step_b = nseq * 2;  // block-to-block distances in bytes ...
+    asm volatile("" : "+s"(ck_step_b), "+s"(eb_step_b));                          // ... kept in SGPRs, not recomputed per block
+    auto uni_piece = [&](const uint64_t lo, const uint64_t hi) {
+        if constexpr (CKPT) {
+            if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
+                if (seg_left == 0) {
+                    if (active && rank == 0) *esp = E;
+                    esp += nseq;
+                    seg_left = A.seg_blocks;
+                }
+                seg_left -= BPC;
+            }
+        }
+        char* ck_u = (char*)((real*)A.ckpt + (int64_t)blk * ck_step);
+        char* eb_u = (char*)(A.eblk + (int64_t)blk * nseq);
+        // (two halves of BPC / 2 blocks: the codes of a block are the low bits of ONE 64-bit scalar, shifted down)
+#pragma nounroll
+        for (int hf = 0; hf < 2; ++hf) {
+            uint64_t cw = hf == 0 ? lo : hi;
+#pragma nounroll
+            for (int bi = 0; bi < BPC / 2; ++bi) {
+                // (the offsets pass through an empty asm: hoisted out of the loop as 64-bit values they would be added
+                // to the base with a v_lshl_add_u64 per store; seen next to the store they are its 32-bit offset operand)
+                asm volatile("" : "+v"(ck_off), "+v"(sq_off));
+                if constexpr (CKPT) {
+#if !PHK_EXP_NO_CKPT_STORE
+#pragma unroll
+                    for (int i = 0; i < SPL; ++i)
+                        *(real*)(ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))) = L::get(a, i);
+#endif
+                    ck_u += ck_step_b;
+                }
+                const int dE = uni_block((uint32_t)cw & (uint32_t)((uint64_t(1) << (2 * T)) - 1u));
+                E += dE;
+                if constexpr (CKPT) {
+                    *(int16_t*)(eb_u + sq_off) = (int16_t)dE;
+                    eb_u += eb_step_b;
+                    eb_min = dE < eb_min ? dE : eb_min;
+                }
+                cw >>= 2 * T;
+            }
+        }
+        blk += BPC;
+        if constexpr (CKPT) {
+            ckp += (int64_t)BPC * ck_step;
+            ebp += (int64_t)BPC * nseq;
+        }
+    };
+    auto lean_piece = [&](const int b) { return b + BPC <= nfull && (blkW < b || blkW >= b + BPC); };
     for (int pc = 0; blk < nblk; pc += PPB) {
+     if constexpr (LEAN && DENSE && PHK_DENSE_UNI != 0 && PHK_UNI_SLOAD != 0) {
+         // Such a wave reads its observation words by SCALAR loads for as long as the pieces are lean: s_load counts
+         // in lgkmcnt, so the wait for the piece requested ahead no longer drains the checkpoint stores (vmcnt counts
+         // loads and stores alike on gfx9, and the compiler cannot count the stores of a piece through its branches:
+         // one store round trip per 64 sites).  No vector load is issued or consumed inside this loop; the piece
+         // after it (warm-up boundary, row tail) is requested again for the general path below.
+         if (uni && lean_ok && lean_piece(blk)) {
+             const ScalarPieces sp = scalar_pieces(pieces);
+             PieceWords snext = sp[pc];
+             do {
+                 PieceWords sc = snext;
+                 // land this piece BEFORE the next one is requested: scalar loads return out of order, s_waitcnt
+                 // lgkmcnt(0) is the only wait they have, and it would wait for the piece requested ahead as well
+                 asm volatile("" : "+s"(sc.x), "+s"(sc.y), "+s"(sc.z), "+s"(sc.w) : : "memory");
+                 snext = sp[pc + 1 < npieces ? pc + 1 : npieces - 1];
+                 uni_piece((uint64_t)sc.x | ((uint64_t)sc.y << 32), (uint64_t)sc.z | ((uint64_t)sc.w << 32));
+                 ++pc;
+             } while (lean_piece(blk));
+             if (blk >= nblk) break;
+             pnext = pieces[pc < npieces ? pc : npieces - 1];
+         }
+     }
      const uint4 c0 = pnext, c1 = nx1, c2 = nx2, c3 = nx3;
      if constexpr (PPB == 4) {  // one wait for all four: none of them is "maybe in flight" inside the q loop
          asm volatile("" ::"v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
@@ -1225,7 +1320,14 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
       const uint4 pcur = PPB == 1 ? c0 : (q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)));
       const int bend = blk + BPC < nblk ? blk + BPC : nblk;
       if constexpr (LEAN) {
-          if (lean_ok && blk + BPC <= nfull && (blkW < blk || blkW >= blk + BPC)) {
+          if (lean_ok && lean_piece(blk)) {
+              if (DENSE && PHK_DENSE_UNI != 0 && uni) {
+                  uni_piece((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32),
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32));
+                  continue;
+              }
               if constexpr (CKPT) {
                   if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
                       if (seg_left == 0) {
@@ -1238,45 +1340,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
               }
               real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
               int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
-              if (DENSE && PHK_DENSE_UNI != 0 && uni) {
-                  // the piece's 64 codes as two scalar 64-bit words, shifted down one block at a time
-                  uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32);
-                  uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32);
-#pragma nounroll
-                  for (int bi = 0; bi < BPC; ++bi) {
-                      if constexpr (CKPT) {
-#if !PHK_EXP_NO_CKPT_STORE
-#pragma unroll
-                          for (int i = 0; i < SPL; ++i) ck_u[ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4)] = L::get(a, i);
-#endif
-                          ck_u += ck_step;
-                      }
-                      const int dE = uni_block((uint32_t)lo & (uint32_t)((uint64_t(1) << (2 * T)) - 1u));
-                      E += dE;
-                      if constexpr (CKPT) {
-                          eb_u[sq_off] = (int16_t)dE;
-                          eb_u += nseq;
-                          eb_min = dE < eb_min ? dE : eb_min;
-                      }
-                      lo = (lo >> (2 * T)) | (hi << (64 - 2 * T));
-                      hi >>= 2 * T;
-                  }
-                  blk += BPC;
-                  if constexpr (CKPT) {
-                      ckp += (int64_t)BPC * ck_step;
-                      ebp += (int64_t)BPC * nseq;
-                  }
-                  continue;
-              }
               uint32_t w0 = pcur.x, w1 = pcur.y, w2 = pcur.z, w3 = pcur.w;
 #pragma nounroll
               for (int bi = 0; bi < BPC; ++bi) {
                   if constexpr (CKPT) {
 #if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
-                      for (int i = 0; i < SPL; ++i) ck_u[ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4)] = L::get(a, i);
+                      for (int i = 0; i < SPL; ++i) *(real*)((char*)ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))) = L::get(a, i);
 #endif
                       ck_u += ck_step;
                   }
@@ -1284,7 +1354,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                   if constexpr (DENSE) dense_block(w0);
                   else straight_block(w0);
                   if constexpr (CKPT) {
-                      eb_u[sq_off] = (int16_t)(E - E0);
+                      *(int16_t*)((char*)eb_u + sq_off) = (int16_t)(E - E0);
                       eb_u += nseq;
                       eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
                   }
@@ -1348,7 +1418,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 real sc;
                 const int ex = lane.fwd_site(a, ring[i % (AH + 1)], sc, rescale_after<NRM>(i));
                 E += ex;
-                if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
+                if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #else
@@ -1363,7 +1433,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                     lane.emis((codes >> (2 * i)) & 3, e);
                     const int ex = lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
                     E += ex;
-                    if (NRM > 1 && rescale_after<NRM>(i)) ex_min = ex < ex_min ? ex : ex_min;
+                    if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
                     if (blk == blkW && i == iW) {
                         const double cW = (double)lane.total(a);
                         llW = log(cW) + (double)E * LN2;
@@ -1381,7 +1451,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
-        (ex_min < (sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64) || exd_min < RISK_EXP_DEFERRED_F32 || !(cend > 0.0)))
+        (ex_slack < 0 || !(cend > 0.0)))
         atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
         A.ll[seq] = log(cend) + (double)E * LN2 - llW;
@@ -1928,7 +1998,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         uni = __all((int)ss == ss0 && lane.etab[0] > RATIO_MIN_EMIS0) != 0;
     }
     int F = 0;
-    int f_min = 0, fd_min = 0;  // dense kernel: smallest exponent removed by a per-group / a deferred rescale (flag: see fwd_kernel)
+    int f_slack = 1 << 20;  // dense kernel: smallest distance to its threshold of an exponent a rescale removed (see fwd_kernel: ex_slack)
     int hom_run = 0;  // dense kernel: rescale debt (hom sites stepped over since the last rescale; uniform path: + 16 per het / missing site)
     // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
     const int nw = (int)((A.Ltot + 15) / 16);
@@ -1970,7 +2040,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                     hom_run = 0;
                     const int ex = lane.rescale(beta);
                     F += ex;
-                    fd_min = ex < fd_min ? ex : fd_min;
+                    f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
                 }
                 return;
             }
@@ -1983,7 +2053,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                         hom_run = 0;
                         const int ex = lane.rescale(beta);
                         F += ex;
-                        fd_min = ex < fd_min ? ex : fd_min;
+                        f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
                     }
                     continue;
                 }
@@ -2010,7 +2080,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                     }
                     const int ex = lane.rescale(beta);
                     F += ex;
-                    f_min = ex < f_min ? ex : f_min;
+                    f_slack = min(f_slack, ex - RISK_EXP_F32);
                 }
             }
         }
@@ -2024,7 +2094,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
             auto resc = [&](float& y) -> int {
                 const int ex = lane.rescale1(y);
                 F += ex;
-                fd_min = ex < fd_min ? ex : fd_min;
+                f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
                 return 0;
             };
             if (__builtin_expect(rem == 0u, 1)) {  // all hom
@@ -2039,7 +2109,46 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
             beta[0][0] = x;
         }
     };
+    // seed of segment sb (beta at site sb * seg_sites) before word w_store is processed
+    auto store_seed = [&]() {
+        real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
+        fseg_out[(int64_t)sb * nseq + seq] = F;
+        --sb;
+        w_store -= seg_words;
+    };
     for (; w >= 0; --pc) {
+      if constexpr (DENSE && PHK_DENSE_LEAN != 0 && PHK_DENSE_UNI_SCAN != 0 && PHK_UNI_SLOAD != 0) {
+          // A wave whose sequences share their observation row reads it by scalar loads from here to the row's start
+          // (every piece left of the one holding the last word is four whole words): see fwd_kernel.  The four words
+          // of a piece, right to left, as the high halves of two 64-bit scalars shifted up.
+          if (uni && w == pc * 4 + 3 && w < nw - 1 && (seg_words & 3) == 0) {
+              const ScalarPieces sp = scalar_pieces(pieces);
+              PieceWords snext = sp[pc];
+              do {
+                  PieceWords sc = snext;
+                  asm volatile("" : "+s"(sc.x), "+s"(sc.y), "+s"(sc.z), "+s"(sc.w) : : "memory");  // (land it before the next request)
+                  snext = sp[pc > 0 ? pc - 1 : 0];
+                  // a seed is stored before word w_store = sb * seg_words - 1 (-1 when none is left: no test of sb), with
+                  // segments of whole pieces always the first word of a piece met from the right: one test per piece
+                  if (__builtin_expect(w == w_store, 0)) store_seed();
+#pragma nounroll
+                  for (int hf = 0; hf < 2; ++hf) {
+                      uint64_t cw = hf == 0 ? ((uint64_t)sc.z | ((uint64_t)sc.w << 32)) : ((uint64_t)sc.x | ((uint64_t)sc.y << 32));
+#pragma nounroll
+                      for (int k = 0; k < 2; ++k, --w) {
+                          uint32_t rem = (uint32_t)(cw >> 32);
+                          asm volatile("" : "+s"(rem));  // (a 32-bit scalar of its own: "rem == 0" is then s_cmp_eq_u32, not a 64-bit VALU compare of cw)
+                          uni_word(rem);
+                          cw <<= 32;
+                      }
+                  }
+                  --pc;
+              } while (w >= 0);
+              break;
+          }
+      }
       const uint4 pcur = pnext;
       pnext = pieces[pc > 0 ? pc - 1 : 0];
       if constexpr (DENSE ? PHK_DENSE_LEAN != 0 : PHK_FWD_LEAN != 0) {
@@ -2117,7 +2226,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
       }
     }
     if constexpr (DENSE) {  // the scan's own underflow flag (its seeds feed the segment sweep; see fwd_kernel for the thresholds)
-        if (active && rank == 0 && A.risk != nullptr && (f_min < RISK_EXP_F32 || fd_min < RISK_EXP_DEFERRED_F32)) atomicOr(A.risk, FLAG_UNDERFLOW);
+        if (active && rank == 0 && A.risk != nullptr && f_slack < 0) atomicOr(A.risk, FLAG_UNDERFLOW);
     }
 }
 

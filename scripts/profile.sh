@@ -24,6 +24,10 @@ if [ "$MODE" = full ]; then
   done
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_SQ" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ.log" 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_SQ2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_SQ2.log" 2>&1
+  # the same static plan timed: per-kernel durations (a kernel trace of its own) and the bench line without a profiler,
+  # so that counters, durations and phase times in the summary all describe one plan
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_static" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace_static.log" 2>&1
+  python3 "$REPO/bench.py" $ARGS > "$OUT/bench_static.json" 2> "$OUT/bench_static.err"
   unset PHK_DETERMINISTIC
 fi
 cd "$REPO"

@@ -72,6 +72,28 @@ for f in find("trace/**/*kernel_trace.csv"):
         print(f"{n[:100]}: n={len(v)} avg_ms={sum(v2) / len(v2) / 1e6:.3f} min_ms={min(v) / 1e6:.3f} max_ms={max(v) / 1e6:.3f} "
               f"compiler: vgpr/agpr/scratch B per lane/waves per SIMD/static lds={regs[n]}")
 print()
+if find("trace_static/**/*kernel_trace.csv"):
+    print("== static plan (PHK_DETERMINISTIC=1, the plan of the counter passes): per-dispatch durations ==")
+    for f in find("trace_static/**/*kernel_trace.csv"):
+        d = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            n = r.get("Kernel_Name", "")
+            if "phk" in n:
+                d[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for n, v in d.items():
+            v2 = sorted(v[2:] if len(v) > 4 else v)
+            print(f"static {n[:100]}: n={len(v)} avg_ms={sum(v2) / len(v2) / 1e6:.3f} median_ms={v2[len(v2) // 2] / 1e6:.3f}")
+    bs = os.path.join(out, "bench_static.json")
+    if os.path.exists(bs):
+        import json
+
+        lines = [ln for ln in open(bs) if ln.startswith("{")]
+        if lines:
+            b = json.loads(lines[-1])
+            k = b["kernel_ms_per_step"]
+            print(f"static bench line (no profiler): ms_per_step={b['ms_per_step']:.3f} forward={k['forward']:.3f} backward={k['backward']:.3f} "
+                  f"steps={b['steps']} warmup={b['warmup']} plan={json.dumps(b['config']['kernel_variant'])}")
+    print()
 print("== PMC counters, averaged per dispatch of each PSMC kernel ==")
 for f in find("pmc_*/**/*counter_collection.csv"):
     acc = defaultdict(lambda: defaultdict(list))
