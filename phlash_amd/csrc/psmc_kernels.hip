@@ -1227,13 +1227,16 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // (lane offsets of the lean stores are 32-bit BYTE offsets beside a wave-uniform base: the store then takes the
     // base from SGPRs -- global_store ... v_off, v_data, s[base] -- and costs no address arithmetic per block)
     const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K * (int64_t)sizeof(real) < (int64_t(1) << 31);
-    unsigned ck_off = (unsigned)L::ck_lane(nseq, seq, rank) * (unsigned)sizeof(real), sq_off = (unsigned)seq * 2u;  // bytes
-    const unsigned ck_piece = (unsigned)(nseq * 4) * (unsigned)sizeof(real);  // distance between the pieces of one sequence (bytes)
+    const unsigned ck_off_e = (unsigned)L::ck_lane(nseq, seq, rank), sq_off_e = (unsigned)seq;
+    const unsigned ck_piece_e = (unsigned)(nseq * 4);  // distance between the pieces of one sequence
+    // (the same in bytes, for uni_piece below)
+    unsigned ck_off = ck_off_e * (unsigned)sizeof(real), sq_off = sq_off_e * 2u;
+    const unsigned ck_piece = ck_piece_e * (unsigned)sizeof(real);
     int blk = 0;
     // one lean piece (64 sites, full blocks, no warm-up boundary) of a wave whose sequences share their observation
     // row: the piece's codes as two scalar 64-bit words, shifted down one block at a time
     int64_t ck_step_b = ck_step * (int64_t)sizeof(real), eb_step_b = nseq * 2;  // block-to-block distances in bytes ...
-    asm volatile("" : "+s"(ck_step_b), "+s"(eb_step_b));                          // ... kept in SGPRs, not recomputed per block
+    if constexpr (DENSE) asm volatile("" : "+s"(ck_step_b), "+s"(eb_step_b));     // ... kept in SGPRs, not recomputed per block
     auto uni_piece = [&](const uint64_t lo, const uint64_t hi) {
         if constexpr (CKPT) {
             if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                   if constexpr (CKPT) {
 #if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
-                      for (int i = 0; i < SPL; ++i) *(real*)((char*)ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))) = L::get(a, i);
+                      for (int i = 0; i < SPL; ++i) ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)] = L::get(a, i);
 #endif
                       ck_u += ck_step;
                   }
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                   if constexpr (DENSE) dense_block(w0);
                   else straight_block(w0);
                   if constexpr (CKPT) {
-                      *(int16_t*)((char*)eb_u + sq_off) = (int16_t)(E - E0);
+                      eb_u[sq_off_e] = (int16_t)(E - E0);
                       eb_u += nseq;
                       eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
                   }

