@@ -464,9 +464,10 @@ def main():
             "plan": [":".join(str(int(v)) for v in row[3:]) for row in allr],
             "plan_fields": ":".join(pkeys),
         }
-    assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
-    assert float(flags[1]) == 0, "a chunk index was out of range"
-    assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
+    if os.environ.get("PHK_BENCH_TIMING_ONLY") != "1":  # (set for timing-only library builds that leave work out: scripts/ab_build.sh)
+        assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
+        assert float(flags[1]) == 0, "a chunk index was out of range"
+        assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
     ranks_identical = None
     if use_dist and world > 1:  # the replicated state must be identical on every rank
         lo, hi = state.particles.clone(), state.particles.clone()
@@ -519,6 +520,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if a.double else "f32",
             "data": "synthetic",
+            **({"timing_only": "PHK_BENCH_TIMING_ONLY=1: result checks skipped, NOT a valid measurement of the shipped library"}
+               if os.environ.get("PHK_BENCH_TIMING_ONLY") == "1" else {}),
             "backend": (a.backend if use_dist else None),
             "rccl_ranks": (dist.get_world_size() if use_dist and a.backend == "nccl" else 0),
             "config": {
