@@ -511,7 +511,9 @@ def test_random_shapes_against_the_oracle(seed):
           f"err/own {r_own:.2e} err/full {r_full:.2e} err/bound {worst:.2f}")
     assert worst < 1.0, f"gradient error {worst:.2f} x its bound ({a:g} x row + {c:g} x whole-row)"
     ll_only = _run(eng, P, inds, W, grad=False)
-    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 1e-5)
+    # (two float32 evaluations by different kernel variants, each held to 1e-5 against the oracle above: they may differ
+    # by twice that -- seed 1422 of the round-4 soak: 2.6e-6 and 1.03e-5 from the oracle, 1.2e-5 apart)
+    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 2e-5)
 
 
 def _runs_data(rng, n, L, het=0.02, miss_runs=3):
