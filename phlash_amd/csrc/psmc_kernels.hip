@@ -66,6 +66,9 @@
                     // (2 leave the block loop of the R = 2 kernel free of scratch accesses, the R = 4 kernel needs 3; 3 is
                     // also 0.2 ms faster than 2 at cfg2: profiles/r03_ab_experiments.txt)
 #endif
+#ifndef PHK_EXP_NO_STEEP
+#define PHK_EXP_NO_STEEP 0
+#endif
 #ifndef PHK_EXP_NO_CKPT_STORE
 #define PHK_EXP_NO_CKPT_STORE 0  // timing-only diagnostic builds: the forward kernel does not store its checkpoints (results are wrong)
 #endif
@@ -1680,7 +1683,11 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     // loop itself carries no test (a per-block test with an exit from the hot loop cost 1.6-2.9 ms at cfg2: the exit
     // edge brought scratch accesses back into the block)
     constexpr int HOT_MIN_EXP = sizeof(real) == 4 ? HOT_BLOCK_MIN_EXP_F32 : HOT_BLOCK_MIN_EXP_F64;
+#if PHK_EXP_NO_STEEP  // timing-only diagnostic builds: every wave takes the hot body (results of steep sequences are wrong)
+    const bool wave_steep = false;
+#else
     const bool wave_steep = HOT_V2 && __any(A.aux[seq].eb_min < HOT_MIN_EXP);
+#endif
     int64_t blk = blk_hi - 1;
     while (blk >= blk_lo) {
         if (!HOT || wave_steep || blk == blkW || blk == blk_part) {
