@@ -53,8 +53,15 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int DEFAULT_NRM = 4;   // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
-constexpr int SEG_SITES = 512;  // sites per segment of the segmented backward
-constexpr int seg_blocks(int T) { return SEG_SITES / T; }  // 64 blocks at T = 8, 32 at T = 16
+// sites per segment of the segmented backward: 512 (64 blocks at T = 8, 32 at T = 16).  PHK_SEG_SITES in the environment
+// (a multiple of 64, read once when the library is loaded) is a developer override for experiments
+static int seg_sites_from_env() {
+    const char* e = std::getenv("PHK_SEG_SITES");
+    const int v = e ? std::atoi(e) : 0;
+    return (v >= 64 && v % 64 == 0 && v <= 65536) ? v : 512;
+}
+static const int SEG_SITES = seg_sites_from_env();
+inline int seg_blocks(int T) { return SEG_SITES / T; }
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 
 struct DevBuf {
