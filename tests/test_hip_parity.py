@@ -611,6 +611,42 @@ def test_dense_kernels_random_shapes(seed):
 
 
 @pytest.mark.parametrize("T", [8, 16])
+def test_scalar_row_loops_at_piece_and_segment_edges(T):
+    """The one-state-per-lane kernels read a wave-uniform observation row by scalar loads inside loops that cover only
+    whole 64-site pieces away from the warm-up boundary and the row's last word; everything else goes through the
+    general loop, and the segment seeds of the beta scan are stored at piece starts.  A grid over exactly those
+    edges -- row lengths around multiples of 64 / 512 / 1,024 sites, the warm-up boundary on, before and after piece
+    and segment edges -- for 8 particles x 2 chunks (two waves per chunk, all of them uniform) at 5 % hets + missing
+    runs, segmented plan (dense forward kernel beside the dense beta scan), against the float64 oracle."""
+    rng = np.random.default_rng(77 + T)
+    B, S = 8, 2
+    P = _params(16, B, 1, seed=3)
+    Pin = P.astype(np.float32).astype(np.float64)
+    worst_all, n = 0.0, 0
+    for L in (64, 65, 127, 128, 129, 511, 512, 513, 576, 1024, 1025, 1088):
+        data = (rng.uniform(size=(S, L)) < 0.05).astype(np.int8)
+        data[0, L // 3:L // 3 + 9] = -1
+        inds = np.arange(S)
+        eng = _engine(16, data, False)
+        eng.set_autotune(False)
+        eng.set_rescale_interval(4)
+        eng.set_plan(1, R=4 if T == 16 else 2, T=T, R_forward=16, R_scan=16)
+        for W in (0, 1, 63, 64, 65, 511, 512, 513):
+            if W >= L:
+                continue
+            ll, g = _run(eng, P, inds, W)
+            ll0 = _run(eng, P, inds, W, grad=False)
+            ll_ref, g_ref = cport.batch(Pin, data, inds, W)
+            np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5, err_msg=f"L={L} W={W}")
+            np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=1e-5, err_msg=f"L={L} W={W} (no-gradient call)")
+            worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
+            assert worst < 1.0, (L, W, worst)
+            worst_all, n = max(worst_all, worst), n + 1
+        assert not eng.underflow_risk()
+    print(f"scalar-row edge grid T={T}: {n} (L, W) cases, worst err/bound {worst_all:.2f}")
+
+
+@pytest.mark.parametrize("T", [8, 16])
 def test_dense_hom_run_operators_f32(T, rng):
     """K = 16, R = 16, float32, rescale interval 4: the forward kernel and the beta scan take M_h^8 / M_h^4 /
     M_h^2 steps wherever all four sequences of a wave are hom over eight / four / two sites.  Mixed waves (one
