@@ -64,12 +64,18 @@ def _oracle_sample(ll, g, P, data, parts, chunks, W, dbl, label):
     return rel, r_bound
 
 
-def _setup(K, B, S, L, W, dbl, seed=0):
+def _setup(K, B, S, L, W, dbl, seed=0, het_rate=None):
     from phlash_amd.engine import HipEngine
     from phlash_amd.params import PSMCParams
     from phlash_amd.synth import particle_population, simulate_chunks
 
-    data = simulate_chunks(K, S, W + L, seed=seed)
+    if het_rate is None:
+        data = simulate_chunks(K, S, W + L, seed=seed)  # rows drawn from the default model: ~1 % hets
+    else:  # i.i.d. hets at a human-like rate + 1 % missing (bench.py --het-rate; the reference's conftest generator)
+        g = np.random.default_rng(1000 + seed)
+        data = (g.random((S, W + L), dtype=np.float32) < het_rate).astype(np.int8)
+        data.flat[g.integers(0, data.size, size=int(0.01 * data.size))] = -1
+        data[:, 0] = np.maximum(data[:, 0], 0)
     tmpl, x = particle_population(K, B, seed=1, sigma=0.25)
     P = PSMCParams.from_dm(tmpl.from_flat(x).to_dm()).stack()[:, None].cuda()
     eng = HipEngine(K, data, double_precision=dbl)
@@ -221,12 +227,12 @@ def _sample_points(eng, B, S, slab_particles=None):
     return sorted(parts), sorted(chunks), plan
 
 
-def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False):
+def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False, het_rate=None):
     """One whole BASELINE config through the float32 kernels at full size: finite everywhere, a bounded
     oracle sample on UNROUNDED float64 parameters (ll <= 1e-5 relative; <= 2e-6 against the oracle fed the rounded
     parameters; gradient rows within a * own + c * whole-row), gradient call == no-gradient call, and
     the two size-independent identities of a W = 0 sweep over the whole batch."""
-    data, P, eng = _setup(K, B, S, L, W, False, seed=seed)
+    data, P, eng = _setup(K, B, S, L, W, False, seed=seed, het_rate=het_rate)
     inds = torch.arange(S, device="cuda")
     ll, g = eng.run(P, inds, W, grad=True)
     assert torch.isfinite(ll).all() and torch.isfinite(g).all()
@@ -276,6 +282,18 @@ def test_production_shape_full_size():
     eng = _full_size_case(16, 500, 5, 100_000, 500)
     plan = eng.get_plan()
     assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
+
+
+@pytest.mark.parametrize("het_rate", [0.05, 0.10])
+def test_production_shape_full_size_at_human_het_rates(het_rate):
+    """The same shape on rows with 5 % / 10 % i.i.d. hets (+ 1 % missing), what human data at 100-bp windows looks
+    like: 37 % / 16 % of the 16-site words are all-hom, so nearly every block of the forward kernel and the beta scan
+    takes the het-terminated dense steps (a run of hom sites ending in a het or missing site = one operator power and
+    one multiply by an emission ratio) -- at full row length against the oracle sample, plus the W = 0 identities."""
+    eng = _full_size_case(16, 500, 5, 100_000, 500, het_rate=het_rate, seed=3)
+    plan = eng.get_plan()
+    assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
+    assert not eng.underflow_risk()
 
 
 def test_cfg3_one_rank_share_through_log_density():
