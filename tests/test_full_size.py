@@ -227,12 +227,14 @@ def _sample_points(eng, B, S, slab_particles=None):
     return sorted(parts), sorted(chunks), plan
 
 
-def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False, het_rate=None):
+def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False, het_rate=None, static_plan=False):
     """One whole BASELINE config through the float32 kernels at full size: finite everywhere, a bounded
     oracle sample on UNROUNDED float64 parameters (ll <= 1e-5 relative; <= 2e-6 against the oracle fed the rounded
     parameters; gradient rows within a * own + c * whole-row), gradient call == no-gradient call, and
     the two size-independent identities of a W = 0 sweep over the whole batch."""
     data, P, eng = _setup(K, B, S, L, W, False, seed=seed, het_rate=het_rate)
+    if static_plan:  # the static rule's plan instead of the tuner's (at cfg2: the dense beta scan whatever the het rate)
+        eng.set_deterministic(True)
     inds = torch.arange(S, device="cuda")
     ll, g = eng.run(P, inds, W, grad=True)
     assert torch.isfinite(ll).all() and torch.isfinite(g).all()
@@ -282,6 +284,16 @@ def test_production_shape_full_size():
     eng = _full_size_case(16, 500, 5, 100_000, 500)
     plan = eng.get_plan()
     assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
+
+
+def test_cfg2_full_size_at_10pct_hets():
+    """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 10 % i.i.d. hets + 1 % missing: the hybrid
+    plan's dense beta scan over the segment-swept range takes het-terminated dense steps in 84 % of its words; oracle
+    sample on both sides of the split, gradient call == no-gradient call, the W = 0 identities over the whole batch."""
+    eng = _full_size_case(16, 100, 500, 60_000, 500, het_rate=0.10, seed=5, static_plan=True)
+    plan = eng.get_plan()
+    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16, plan
+    assert not eng.underflow_risk()
 
 
 @pytest.mark.parametrize("het_rate", [0.05, 0.10])
