@@ -286,6 +286,29 @@ def test_production_shape_full_size():
     assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
 
 
+def test_whole_chromosome_row_as_the_held_out_kernel_sees_it():
+    """A held-out contig is ONE row per sample at full length with a single all-missing warm-up column
+    (mcmc.py:230-233): 3,000,001 windows (300 Mb at 100 bp) x 8 particles, 5 % hets.  The no-gradient forward kernel
+    (what the expected log-predictive density runs) and the gradient call -- 5,860 segments per sequence, 375,000
+    checkpoint blocks, observation words far past 2^16 -- against the float64 oracle."""
+    L, W, B = 3_000_001, 1, 8
+    data, P, eng = _setup(16, B, 1, L, W, False, seed=9, het_rate=0.05)
+    data[:, 0] = -1  # the reference's warm-up column
+    from phlash_amd.engine import HipEngine
+
+    eng = HipEngine(16, data, double_precision=False)
+    inds = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ll0 = eng.run(P, inds, W, grad=False)
+    ll, g = eng.run(P, inds, W, grad=True)
+    assert torch.isfinite(ll0).all() and torch.isfinite(ll).all() and torch.isfinite(g).all()
+    _oracle_sample(ll, g, P, data, [0, B - 1], [0], W, False, f"one row of {L} sites")
+    ll_ref = cport.batch(P.double().cpu().numpy(), data, [0], W, grad=False)
+    rel0 = float(np.abs(ll0.cpu().numpy() / ll_ref - 1).max())
+    print(f"PARITY one row of {L} sites, no-gradient call, all {B} particles: ll rel {rel0:.2e}")
+    assert rel0 < F32_LL_UNROUNDED, rel0
+    assert not eng.underflow_risk()
+
+
 def test_cfg2_full_size_at_10pct_hets():
     """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 10 % i.i.d. hets + 1 % missing: the hybrid
     plan's dense beta scan over the segment-swept range takes het-terminated dense steps in 84 % of its words; oracle
