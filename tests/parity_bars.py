@@ -56,6 +56,8 @@ BARS = {  # name: bar                                  measured worst (round 4: 
     "ref_cuda.live_short.f64": 8e-14,              # 1.62e-14
     "ref_cuda.live_cfg2_rows.f32": 0.00039,         # 7.92e-05
     "ref_cuda.live_cfg2_rows.f64": 3e-13,          # 6.11e-14
+    "ref_cuda.live_dense_het_runs.f32": 2.1e-5,    # 4.25e-6 (20,000-site rows at 5 % / 10 % hets, one-state-per-lane kernels)
+    "ref_cuda.live_dense_het_runs.f64": 2.5e-13,   # 5.13e-14
     "golden.row0.f32": 2.5e-5,                     # 5.03e-6
     "golden.row0.f64": 4e-14,                      # 8.0e-15
     "golden.row1_W100.f32": 1.5e-5,                # 3.05e-6 of (own row + W = 0 row)

@@ -187,6 +187,41 @@ def test_hip_vs_live_reference_kernels_random_inputs(K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("het_rate", [0.05, 0.10])
+def test_hip_dense_het_runs_vs_live_reference_kernels(het_rate):
+    """The production-shaped plan in small: 8 particles (two full waves per chunk, every wave on one observation row)
+    x 3 chunks of 20,000 sites with 5 % / 10 % i.i.d. hets + 1 % missing, one parameter block per particle.  The
+    float32 one-state-per-lane forward kernel and beta scan take het- and missing-terminated runs as dense operator
+    steps here; log-likelihood and d ll / d log(param) against the reference's float64 gradient kernel, run live."""
+    import torch
+
+    if not refcuda.available(16, True):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    K, B, S, L = 16, 8, 3, 20_000
+    rng = np.random.default_rng(int(het_rate * 1000))
+    data = (rng.uniform(size=(S, L)) < het_rate).astype(np.int8)
+    data.flat[rng.integers(0, data.size, size=data.size // 100)] = -1
+    data[:, 0] = np.maximum(data[:, 0], 0)
+    blocks = []
+    for _ in range(B):
+        dm = o.default_dm(f"{K}*1", 1e-2, 1e-2)
+        dm = dm._replace(c=dm.c * np.exp(rng.normal(size=K) * 0.4))
+        blocks.append(o.from_dm(dm).stack())
+    PB = np.repeat(np.stack(blocks)[:, None], S, axis=1)  # [B, S, 7, K] for the reference kernel
+    inds = np.arange(S)
+    ll_r, dlog_r, _ = refcuda.call(K, True, data, inds, PB, grad=True)
+    for dbl in (True, False):
+        eng = _engine(K, data, dbl)
+        ll_h, dlog_h = eng.run(torch.tensor(PB[:, :1], device="cuda"), torch.tensor(inds, device="cuda"), 0, grad=True, dlog=True)
+        plan = eng.get_plan()
+        if not dbl:
+            assert plan["segmented"] == 1 and plan["R_forward"] == 16 and plan["R_scan"] == 16, plan
+        np.testing.assert_allclose(ll_h.cpu().numpy(), ll_r, rtol=1e-11 if dbl else 1e-5)
+        check(f"ref_cuda.live_dense_het_runs.{'f64' if dbl else 'f32'}", _rowscaled(dlog_h.double().cpu().numpy(), dlog_r))
+        assert not eng.underflow_risk()
+
+
+@pytest.mark.gpu
 def test_reference_nograd_kernel_equals_its_grad_kernel():
     # tests/test_gpu.py:33-40 of the reference, on its own kernels
     if not refcuda.available(16, True):
