@@ -87,6 +87,14 @@ class _NoRows:
         assert bad == 0, "a chunk index was out of range on another rank"
         return under > 0
 
+    def begin_check(self, also):  # (the two halves of check_rescaling, as PSMCKernel has them)
+        flags, self._flags = self._flags, None
+        return flags, also
+
+    def finish_check(self, pending) -> bool:
+        self._flags, also = pending
+        return self.check_rescaling(collective=True, also=also)
+
 
 def _join_process_group(device=None) -> int:
     """Under torchrun (RANK / WORLD_SIZE in the environment) bind this process to GPU LOCAL_RANK and
@@ -375,6 +383,52 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     ends = np.cumsum([len(v) for v in shares])
     dev_inds = [flat_dev[(ends[k - 1] if k else 0):ends[k]] for k in range(niter)]
 
+    # The held-out evaluation is ONE dependent chain per particle over a whole contig (a row is scored at full length:
+    # mcmc.py:230-233) -- 8 ms for 400,000 windows, 60 ms for a 300 Mb chromosome, with the chip nearly idle -- and its
+    # value is only needed to decide whether to stop.  So it runs on a stream of its own from the state it was asked
+    # about while the sampler goes on, and is read ten iterations later (at the same iteration on every rank), before
+    # the next one starts.  Should the reference's rule have stopped at the iteration it belongs to, the iterations
+    # run since are dropped and the state of that iteration is returned: the result is the one the synchronous loop
+    # gives, bit for bit (tests/test_kernel_api.py), up to ten speculative iterations are the price.  Off with a callback
+    # (it must see every iteration once, in order) or ``speculative_elpd=False``.
+    speculative = elpd is not None and cb is None and bool(options.get("speculative_elpd", True))
+    elpd_stream = torch.cuda.Stream(dev) if speculative else None
+    # (its all-reduce waits for the whole evaluation: a communicator of its own, or the sampler's all-reduces, issued
+    # later, would queue behind it -- parallel.use_group.  Every rank creates the group here, in the same order.)
+    elpd_group = dist.new_group() if speculative and size > 1 else None
+    elpd_pending = None  # (iteration, state at that iteration, kernel object, flags + value on their way to the host)
+
+    def judge_elpd(i0, e) -> bool:
+        """The reference's early-stopping rule (mcmc.py:224-238) for the evaluation of iteration ``i0``."""
+        nonlocal ema, best_elpd
+        ema = e if ema is None else 0.9 * ema + 0.1 * e
+        if best_elpd is None or ema > best_elpd[1]:
+            best_elpd = (i0, ema)
+        return i0 - best_elpd[0] > elpd_cutoff
+
+    def launch_elpd(i0):
+        elpd_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(elpd_stream), parallel.use_group(elpd_group):
+            val, k_ = elpd_once(state.particles)
+            chk = k_.begin_check(also=val)
+        return i0, state, k_, chk
+
+    def collect_elpd() -> bool:
+        """Reads the evaluation under way; True = the rule stops at ITS iteration: ``state`` goes back to that one."""
+        nonlocal state, pending, elpd_pending
+        i0, st0, k_, chk = elpd_pending
+        elpd_pending = None
+        if k_.finish_check(chk):  # extreme particles: once more with per-site rescaling, at once
+            torch.cuda.current_stream(dev).wait_stream(elpd_stream)
+            e = elpd(st0.particles)
+        else:
+            e = k_.also_value
+        if judge_elpd(i0, e):
+            pending = None  # (the unchecked step in flight belongs to the iterations that are dropped)
+            state = st0
+            return True
+        return False
+
     for i in it:
         inds = dev_inds[i]
         if not lag:
@@ -391,14 +445,17 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                 state = new_state
         if elpd is not None and i % 10 == 0:
             settle()
-            e = elpd(state.particles)
-            ema = e if ema is None else 0.9 * ema + 0.1 * e
-            if best_elpd is None or ema > best_elpd[1]:
-                best_elpd = (i, ema)
-            if i - best_elpd[0] > elpd_cutoff:
-                break
+            if not speculative:
+                if judge_elpd(i, elpd(state.particles)):
+                    break
+            else:
+                if elpd_pending is not None and collect_elpd():
+                    break
+                elpd_pending = launch_elpd(i)
         if cb is not None:
             cb(dms(state.particles))
+    if elpd_pending is not None:  # (the loop ran out with one evaluation still under way)
+        collect_elpd()
     settle()
 
     out = dms(state.particles)

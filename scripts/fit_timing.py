@@ -19,17 +19,26 @@ L = 2_000_000  # windows per contig -> 20 chunks of 100,000 each
 contigs = [RawContig(het_matrix=(rng.uniform(size=(1, L)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
            for _ in range(3)]
 held_out = RawContig(het_matrix=(rng.uniform(size=(1, 400_000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
-def run(test, n):
+# a whole chromosome as the held-out row (250 Mb at 100-bp windows): what a real run hands to test_data
+chromosome = RawContig(het_matrix=(rng.uniform(size=(1, 2_500_000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
+
+
+def run(test, n, **kw):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fit(contigs, test_data=test, key=1, niter=n, chunk_size=100_000, overlap=500, minibatch_size=5, num_particles=500,
-        progress=False, elpd_cutoff=10 ** 9)
+        progress=False, elpd_cutoff=10 ** 9, **kw)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
 
-for test in (None, held_out):
-    run(test, 20)  # warm-up (library load, allocator)
-    a, b = run(test, niter), run(test, 3 * niter)
-    print(f"held-out={'yes' if test is not None else 'no '}: {niter} iterations {a:.2f} s, {3 * niter} iterations {b:.2f} s -> "
+cases = [("held-out=no ", None, {}),
+         ("held-out=400,000 windows, evaluated beside the sampler (default)", held_out, {}),
+         ("held-out=400,000 windows, evaluated in line (speculative_elpd=False)", held_out, {"speculative_elpd": False}),
+         ("held-out=2,500,000 windows, beside the sampler (default)", chromosome, {}),
+         ("held-out=2,500,000 windows, in line (speculative_elpd=False)", chromosome, {"speculative_elpd": False})]
+for name, test, kw in cases:
+    run(test, 20, **kw)  # warm-up (library load, allocator)
+    a, b = run(test, niter, **kw), run(test, 3 * niter, **kw)
+    print(f"{name}: {niter} iterations {a:.2f} s, {3 * niter} iterations {b:.2f} s -> "
           f"{(b - a) / (2 * niter) * 1e3:.2f} ms per iteration, {a - (b - a) / 2:.2f} s of set-up (chunking, upload, tuning)", flush=True)

@@ -201,6 +201,42 @@ def test_fit_reads_flags_one_step_late_with_the_same_result(monkeypatch, flag_at
     assert out[False][3] == 6 + extra and out[True][3] == 6 + extra * (1 if flag_at == 5 else 2)
 
 
+@pytest.mark.parametrize("cutoff,niter", [(100, 25), (-1, 25), (9, 45), (19, 45), (100, 31)])
+def test_speculative_held_out_evaluation_gives_the_synchronous_result(monkeypatch, cutoff, niter):
+    """fit() scores the held-out contig on a stream of its own while the sampler goes on and reads the value ten
+    iterations later; if the early-stopping rule (mcmc.py:224-238) fires for the iteration the value belongs to, the
+    iterations run since are dropped.  The models returned are the synchronous loop's to the last bit: no stop
+    (cutoff 100), a stop at the first evaluation (cutoff -1), stops wherever the smoothed score stalls (cutoffs 9 /
+    19), a run that ends with an evaluation still under way (31 iterations) -- and the number of held-out
+    evaluations is the same."""
+    from phlash_amd.data import RawContig
+    from phlash_amd.kernel import PSMCKernel
+    from phlash_amd.mcmc import fit
+
+    rng = np.random.default_rng(4)
+    contigs = [RawContig(het_matrix=(rng.uniform(size=(1, 9000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
+               for _ in range(3)]
+    held_out = RawContig(het_matrix=(rng.uniform(size=(1, 30_000)) < 0.05).astype(np.int8), afs=np.ones(1), window_size=100)
+    out = {}
+    orig = PSMCKernel.value
+    for spec in (False, True):
+        calls = {"n": 0}
+
+        def counted(self, *a, calls=calls, **k):  # (the no-gradient evaluation: only the held-out kernel object runs it)
+            calls["n"] += 1
+            return orig(self, *a, **k)
+
+        monkeypatch.setattr(PSMCKernel, "value", counted)
+        res = fit(contigs, test_data=held_out, key=5, niter=niter, overlap=100, chunk_size=2900, num_particles=24,
+                  minibatch_size=3, progress=False, deterministic=True, elpd_cutoff=cutoff, speculative_elpd=spec)
+        out[spec] = (torch.stack([r.eta.c for r in res]), torch.stack([r.eta.t for r in res]), [r.rho for r in res], calls["n"])
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    if cutoff == -1:  # stopped at iteration 0: one evaluation in the synchronous loop, two launched in the other
+        assert out[False][3] == 1 and out[True][3] <= 2
+    if cutoff == 100:
+        assert out[True][3] == out[False][3] == (niter + 9) // 10
+
+
 def test_out_of_range_chunk_index():
     """gpu.py:197-199 asserts 0 <= index < N on the host.  Host indices are checked the same way; indices
     that live on the device are checked by the kernels (clamped to row 0, sticky flag) and reported at
