@@ -21,7 +21,9 @@ Differences from the reference, all deliberate:
   ranks return the same particles.  ``fit`` joins the process group itself when it finds torchrun's
   environment (RANK / WORLD_SIZE / LOCAL_RANK) and nobody has initialised ``torch.distributed`` yet:
   backend "nccl" (= RCCL) bound to GPU LOCAL_RANK.  The reference drives all GPUs from one process
-  with threads instead (gpu.py:386-438).
+  with threads instead (gpu.py:386-438);
+* the flags of a step are read one step late and the held-out score ten iterations late, both with a roll-back
+  that keeps the results those of the reference's schedule (``lagged_check``, ``speculative_elpd``).
 """
 
 from __future__ import annotations
@@ -152,6 +154,10 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
             elpd_cutoff=100, afs_transform, minibatch_size, init, theta, t1=1e-4, tM=15.0,
             rho_over_theta=1.0, alpha=0, beta=0, learning_rate=0.1, sigma=1.0, num_particles=500,
             double_precision=False, callback, progress=True.
+            Extensions: shard, deterministic, device, fused_step, lagged_check,
+            speculative_elpd (default on: the held-out score runs beside the sampler and is read ten
+            iterations later; a stop it asks for rolls back to its iteration, so the result is the in-line
+            loop's).
 
     Returns:
         list of ``DemographicModel`` (one per particle), rates per base pair.
