@@ -451,7 +451,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                 state = new_state
         if elpd is not None and i % 10 == 0:
             settle()
-            if not speculative:
+            if not speculative or i == 0:  # (the first one in line: the held-out kernel object tunes its plan undisturbed)
                 if judge_elpd(i, elpd(state.particles)):
                     break
             else:
