@@ -220,16 +220,15 @@ int64_t n_units(const phk_handle* h, int T, int64_t W) {
     return nseg - segW;
 }
 
-// The one-state-per-lane beta scan with its dense hom-run steps (K = 16, float32, rescale interval 4) pays inside the
-// hybrid plan only if the four sequences of a wave read the SAME chunk (the wave vote for a dense step then succeeds
-// as often as one sequence alone would), i.e. if the segment-swept range is a range of whole particles:
-// psmc_kernels.hip maps such a range chunk-major.  So a hybrid plan that asks for R2 = 16 gets its split rounded down
-// to a multiple of S -- unless that takes more than 2 % of the serial sweep's sequences away (then R2 = 2, the
-// structured scan, with the split as it was).  Measured at cfg2: beta scan 14.0 -> 12.2 ms, step -1.1 ms.
+// The one-state-per-lane beta scan with its dense steps (K = 16, float32, rescale interval 4) pays inside the hybrid
+// plan only if the four sequences of a wave read the SAME chunk (the codes are then scalars and every run of sites one
+// dense step).  Sequences are stored chunk-major (psmc_kernels.hip, SeqMap), so that holds for a segment-swept range of
+// whole chunks: a hybrid plan that asks for R2 = 16 gets its split rounded down to a multiple of B -- unless that takes
+// more than 2 % of the serial sweep's sequences away (then R2 = 2, the structured scan, with the split as it was).
 bool dense_scan_ok(const phk_handle* h) { return h->K == 16 && !h->dbl && h->nrm == 4 && valid_Rf(h, 16); }
-Plan adjust_hybrid(const phk_handle* h, Plan p, int64_t S) {
+Plan adjust_hybrid(const phk_handle* h, Plan p, int64_t B) {
     if (p.segmented || p.hybrid_first <= 0 || p.R2 != 16) return p;
-    const int64_t rect = S > 0 ? (p.hybrid_first / S) * S : 0;
+    const int64_t rect = B > 0 ? (p.hybrid_first / B) * B : 0;
     if (dense_scan_ok(h) && rect > 0 && (p.hybrid_first - rect) * 50 <= p.hybrid_first) p.hybrid_first = rect;
     else p.R2 = valid_Rf(h, 2) ? 2 : p.R2;
     return p;
@@ -558,8 +557,8 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
                 hyb.hybrid_first = first;
                 hyb.R3 = c[0];
                 hyb.R2 = c[1];
-                hyb = adjust_hybrid(h, hyb, a.S);
-                if (c[1] == 16 && hyb.R2 != 16) continue;  // (the split cannot be a range of whole particles here)
+                hyb = adjust_hybrid(h, hyb, a.B);
+                if (c[1] == 16 && hyb.R2 != 16) continue;  // (the split cannot be a range of whole chunks here)
                 float ms = 0.f;
                 if ((rc = timed(a, hyb, true, &ms)) != PHK_OK) return rc;
                 if (verbose) std::fprintf(stderr, "phk tune: nseq %lld hybrid first %lld sweep R=%d scan R=%d at full length: %.3f ms\n", (long long)nseq, (long long)hyb.hybrid_first, hyb.R3, hyb.R2, ms);
@@ -1168,7 +1167,7 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         int rc = autotune(h, l, make_args(0, std::min(Bs, B), 0, std::min(Ss, S)), want_grad, st);
         if (rc != PHK_OK) return rc;
     }
-    const Plan plan = adjust_hybrid(h, choose_plan(h, nseq_launch, W, want_grad ? 1 : 0), std::min(Ss, S));
+    const Plan plan = adjust_hybrid(h, choose_plan(h, nseq_launch, W, want_grad ? 1 : 0), std::min(Bs, B));
     if (!(want_grad ? (plan.segmented ? valid_Rs(h, plan.R) : valid_Rb(h, plan.R)) : valid_Rf(h, plan.R)) || !valid_T(K, plan.R, plan.T))
         return fail(PHK_EINVAL, "R=%d T=%d not available for K=%d", plan.R, plan.T, K);
     if (want_grad && !plan.segmented && plan.hybrid_first > 0 && !valid_Rs(h, plan.R3)) return fail(PHK_EINVAL, "segment sweep R=%d not available for K=%d", plan.R3, K);

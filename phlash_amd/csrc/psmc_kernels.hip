@@ -37,6 +37,7 @@
 // re-run ending in the same scaling as the next checkpoint).
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #ifndef PHK_EXP_LAND_F64
@@ -62,9 +63,12 @@
 #define PHK_SWEEP_V2 1  // backward kernel, full blocks: beta pass first (storing w = e.*beta), then the forward re-run accumulates
 #endif
 #ifndef PHK_PARK
-#define PHK_PARK 3  // PHK_SWEEP_V2 with 8 float32 states per lane: this many of a block's 8 w vectors live in LDS, not registers
-                    // (2 leave the block loop of the R = 2 kernel free of scratch accesses, the R = 4 kernel needs 3; 3 is
-                    // also 0.2 ms faster than 2 at cfg2: profiles/r03_ab_experiments.txt)
+#define PHK_PARK 1  // PHK_SWEEP_V2 with 8 float32 states per lane: this many of a block's 8 w vectors live in LDS, not registers.
+                    // Round 3 needed 3 to keep the block loop free of scratch; the folded body (round 5) has no emission rows
+                    // in flight and its mass rows in LDS, and 1 is enough -- and it keeps the slice of a 256-thread workgroup
+                    // under the 64 KB a launch gets without asking: with 2 or 3 the launcher falls back to 128-thread
+                    // workgroups, whose two waves land on one SIMD (cfg2 backward phase 25.1 instead of 20.1 ms,
+                    // profiles/r05_ab_experiments.txt item 2)
 #endif
 #ifndef PHK_EXP_NO_STEEP
 #define PHK_EXP_NO_STEEP 0
@@ -93,6 +97,12 @@ __device__ __forceinline__ int frexp_exp_(float x) { return __builtin_amdgcn_fre
 __device__ __forceinline__ int frexp_exp_(double x) { return __builtin_amdgcn_frexp_exp(x); }
 __device__ __forceinline__ float ldexp_(float x, int e) { return __builtin_ldexpf(x, e); }
 __device__ __forceinline__ double ldexp_(double x, int e) { return __builtin_ldexp(x, e); }
+
+// byte offset of an LDS location inside the workgroup's allocation (what ds_* instructions take as their address)
+template <typename T>
+__device__ __forceinline__ uint32_t lds_addr(const T* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) T*)p;
+}
 
 // DPP move with zero fill for lanes whose source is outside the 16-lane row.
 // BANKS: 4-bit mask over the four 4-lane banks of a row; lanes of a disabled bank also get zero.
@@ -259,6 +269,15 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #ifndef PHK_DENSE_UNI
 #define PHK_DENSE_UNI 1  // A/B: 0 = waves with one observation row take the wave-vote path like any other
 #endif
+#ifndef PHK_FOLD
+#define PHK_FOLD 1  // A/B: 0 = no float32 kernel folds its hom emission into the factors
+#endif
+#ifndef PHK_SWEEP_FOLD
+#define PHK_SWEEP_FOLD PHK_FOLD  // A/B: 0 = the sweeps' hot body keeps its per-site emission rows (the model is folded all the same)
+#endif
+#ifndef PHK_FWD_FOLD
+#define PHK_FWD_FOLD PHK_FOLD  // A/B: 0 = the forward kernels with several states per lane have no emission-free block
+#endif
 #ifndef PHK_UNI_SLOAD
 #define PHK_UNI_SLOAD 1  // A/B: 0 = such waves read their observation words by vector loads like the others
 #endif
@@ -363,6 +382,51 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
                 etab_thread[1 * EROW + 2 * h + c] = ok ? q[5 * K + i] : real(1);
                 etab_thread[2 * EROW + 2 * h + c] = real(1);
             }
+        }
+    }
+
+    // Forward kernel, float32: alpha' = e .* (d .* alpha + v .* pre + b .* suf), so the hom emission can live inside
+    // the factors (b, d, v) <- emis0 .* (b, d, v) and the table rows become what is left to multiply by: 1 for a hom
+    // site, emis1 / emis0 for a het, 1 / emis0 for a missing one.  Every code path of the kernel stays what it is (it
+    // multiplies by its site's row), and a site known to be hom for the whole wave multiplies by nothing and reads no
+    // row at all (fwd_site<false>).  Only where the ratios exist: see RATIO_MIN_EMIS0.
+    // (decided per SEQUENCE -- all R lanes of the group agree -- so that what is computed for a sequence does not
+    // depend on which other sequences share its wave)
+    __device__ __forceinline__ bool emissions_foldable() const {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < EROW; ++i) ok = ok && etab[i] > (real)RATIO_MIN_EMIS0;
+        return g.sum(ok ? real(0) : real(1)) == real(0);
+    }
+    __device__ __forceinline__ void fold_emissions() {
+        real* t = const_cast<real*>(etab);
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const V e0 = ((const V*)t)[h];
+            const V e1 = ((const V*)(t + EROW))[h];
+            b[h] = b[h] * e0;
+            d[h] = d[h] * e0;
+            v[h] = v[h] * e0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                t[0 * EROW + 2 * h + c] = real(1);
+                t[1 * EROW + 2 * h + c] = (real)((double)e1[c] / (double)e0[c]);
+                t[2 * EROW + 2 * h + c] = (real)(1.0 / (double)e0[c]);
+            }
+        }
+    }
+    // Every float32 kernel -- forward, beta scan, sweeps, every variant -- runs on the folded model whenever the
+    // sequence's ratios exist: the kernels of one evaluation must agree on the factors to the last bit, or the forward
+    // kernel's alpha and the sweep's beta belong to two HMMs that differ by one rounding per factor, a difference
+    // that is the same at every site and adds up along the row (60,000 sites: sum(alpha .* beta) drifts 6e-4 from 1
+    // and takes every gradient row with it).  float64 kernels keep their emissions in the table.
+    __device__ __forceinline__ bool try_fold() {
+        if constexpr (sizeof(real) == 4 && PHK_FOLD != 0) {
+            const bool ok = emissions_foldable();
+            if (ok) fold_emissions();
+            return ok;
+        } else {
+            return false;
         }
     }
 
@@ -538,7 +602,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // the prologue of every wave (float64 products over DPP broadcasts: ~5,000 instructions, 1.4 KB of scratch per
     // lane); with all eight powers that prologue outgrew the 2,048-site problem the tuner times these kernels on.
     template <bool NEED16>
-    __device__ __forceinline__ void load_dense(const float* __restrict__ ops, int rank) {
+    __device__ __forceinline__ void load_dense(const float* __restrict__ ops, int rank, const bool folded) {
         if constexpr (has_dense<real, K, R>()) {
             const float4* src = (const float4*)(ops + rank * 16);
 #pragma unroll
@@ -562,9 +626,10 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
                     this->D16[4 * q + 3] = v4.w;
                 }
             }
+            // (a folded lane's table already holds the ratios: rows 1 and 2)
             const double e0 = (double)etab[0], e1 = (double)etab[EROW];
-            this->rhet = (float)(e1 / e0);
-            this->rmis = (float)(1.0 / e0);
+            this->rhet = folded ? etab[EROW] : (float)(e1 / e0);
+            this->rmis = folded ? etab[2 * EROW] : (float)(1.0 / e0);
             // (pinned: left alone the compiler sinks the divisions into the site loop to save two registers)
             asm volatile("" : "+v"(this->rhet), "+v"(this->rmis));
         }
@@ -737,6 +802,9 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // One forward site (hmm.py:74-79): a <- (a A) .* e_code, then, if SCALE, a *= 2^-ex with ex the
     // exponent of the sum (so that sum(a) lands in [0.5,1)); returns ex (0 if !SCALE) and the scale.
     // code: 0 hom, 1 het, 2 missing (emission 1; hmm.py:70-71)
+    // (EMIS = false: a hom site of a lane whose hom emission is folded into b, d, v -- fold_emissions -- multiplies
+    // by nothing)
+    template <bool EMIS = true>
     __device__ __forceinline__ int fwd_site(V (&a)[NP], const V (&e)[NP], real& scale, const bool SCALE) const {
         V pre[NP], suf[NP];
         scans(a, pre, suf);
@@ -745,7 +813,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
             V t = d[h] * a[h];
             t = fma2<real>(v[h], pre[h], t);
             t = fma2<real>(b[h], suf[h], t);
-            a[h] = t * e[h];
+            a[h] = EMIS ? t * e[h] : t;
         }
         if (SCALE) {
             const real c = total(a);
@@ -767,9 +835,9 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     //   g0/g1 += aq.*beta  (divided by emis0/emis1 at the end)         with w = e.*beta*s
     __device__ __forceinline__ void bwd_site(const V (&ap)[NP], const V (&aq)[NP], V (&beta)[NP], const V (&e)[NP],
                                              int code, real s, const bool SCALE, V (&gb)[NP], V (&gd)[NP], V (&gu)[NP],
-                                             V (&gv)[NP], V (&g0)[NP], V (&g1)[NP]) const {
+                                             V (&gv)[NP], V (&g0)[NP], V (&g1)[NP], const int g0code = 0) const {
         const V f1 = splat<real>(code == 1 ? real(1) : real(0));
-        const V f0 = splat<real>(code == 0 ? real(1) : real(0));
+        const V f0 = splat<real>(code == g0code ? real(1) : real(0));  // (folded form: g0 collects the mass at MISSING sites)
         V pre[NP], suf[NP], w[NP];
         scans(ap, pre, suf);
 #pragma unroll
@@ -823,6 +891,10 @@ struct SeqAux {      // written by the forward kernel, read by the backward kern
     int32_t e_end;   // exponent total E after the last site: true alpha_L = alpha * 2^E
     int32_t eb_min;  // smallest exponent total of any checkpoint block of the sequence (<= 0).  REQUIRED of every producer
                      // of checkpoints: bwd_kernel decides from it whether the wave may take its unscaled hot body
+    int32_t folded;  // written by the segment sweep: 0 = its partial sums are d ll / d(parameter) as they stand; 1 / 2 = they
+                     // are those of the folded model (see bwd_kernel; 1: hom mass = remainder, 2: booked directly) and
+                     // grad_unfold_kernel converts them after grad_finalize_kernel
+    int32_t pad_;
 };
 
 struct KArgs {
@@ -850,7 +922,7 @@ struct KArgs {
     const int32_t* fseg;     // [nseg+1, B*S] its exponents
     double* bpi;             // [B*S, K] d ll / d pi (segmented mode; the serial kernel writes grad itself)
     int* risk;               // set to 1 if a rescale ever found the mass below 2^RISK_EXP (see below)
-    // Sub-range [seq_begin, seq_end) of the sequences (storage index b * S + s) this launch covers;
+    // Sub-range [seq_begin, seq_end) of the sequences (chunk-major storage index s * B + b: see SeqMap) this launch covers;
     // seq_end == 0 means all.  The hybrid plan sweeps one range serially and the other by segments;
     // every per-sequence array keeps its full B*S layout.
     int64_t seq_begin, seq_end;
@@ -969,17 +1041,33 @@ __device__ __forceinline__ ScalarPieces scalar_pieces(const uint4* p) {
     return (ScalarPieces)(((uint64_t)hi << 32) | lo);
 }
 
+// Sequence order.  Every per-sequence array the kernels keep for themselves (checkpoints, block and segment
+// exponents, segment seeds, partial sums, aux) is indexed CHUNK-MAJOR: seq = s * B + b, and launches cover ranges
+// [seq_begin, seq_end) of that order.  Adjacent lanes then hold adjacent particles of ONE chunk: a wave reads one
+// observation row (two where it crosses a chunk boundary), which is what lets the forward kernel take its codes as
+// scalars (uni2 below), and the checkpoint pieces of a wave stay neighbours in memory.  Only what the caller reads --
+// ll [B, S], grad [B, S, 7, K] -- is particle-major: oseq = b * S + s.
+__device__ __forceinline__ ScalarPieces scalar_pieces_of_lane(const uint4* p, const int lane_id) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a, lane_id);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(a >> 32), lane_id);
+    return (ScalarPieces)(((uint64_t)hi << 32) | lo);
+}
+
 struct SeqMap {
-    int64_t bb, ss, seq;
+    int64_t bb, ss, seq, oseq;
     bool active;     // this group holds a sequence of its own
     bool idle_wave;  // no group of this wave does: the wave must leave (see fwd_kernel)
 };
+// The one-state-per-lane kernels (four lane groups per wave) want the four sequences of a wave on ONE chunk: over a
+// range of whole chunks every chunk's particles are padded to a multiple of four groups (the padding groups repeat the
+// chunk's last particle).
 template <typename real, int K, int R>
 __host__ __device__ inline int64_t launch_groups(const KArgs& A) {  // lane groups a launch needs (grid = this / groups per workgroup)
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
-    if (has_dense<real, K, R>() && A.S > 0 && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {
-        const int64_t nb = (seq_hi - A.seq_begin) / A.S;
-        return A.S * ((nb + 3) & ~int64_t(3));
+    if (has_dense<real, K, R>() && A.B > 0 && (A.B & 3) != 0 && A.seq_begin % A.B == 0 && seq_hi % A.B == 0) {
+        const int64_t ns = (seq_hi - A.seq_begin) / A.B;
+        return ns * ((A.B + 3) & ~int64_t(3));
     }
     return seq_hi - A.seq_begin;
 }
@@ -989,21 +1077,22 @@ __device__ __forceinline__ SeqMap map_group(const KArgs& A) {
     const int64_t g = (int64_t)blockIdx.x * (blockDim.x / R) + threadIdx.x / R;               // this group, within the launch
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x / R) + (int64_t)((threadIdx.x & ~63u) / R);  // the wave's first group
     SeqMap m;
-    if (has_dense<real, K, R>() && A.seq_begin % A.S == 0 && seq_hi % A.S == 0) {  // a range of whole particles
-        const int64_t b0 = A.seq_begin / A.S, nb = (seq_hi - A.seq_begin) / A.S, nbp = (nb + 3) & ~int64_t(3);
+    if (has_dense<real, K, R>() && (A.B & 3) != 0 && A.seq_begin % A.B == 0 && seq_hi % A.B == 0) {  // whole chunks, padded
+        const int64_t s0 = A.seq_begin / A.B, ns = (seq_hi - A.seq_begin) / A.B, nbp = (A.B + 3) & ~int64_t(3);
         const int64_t sc = g / nbp, r = g - sc * nbp;
-        m.idle_wave = gw >= A.S * nbp;
-        m.active = sc < A.S && r < nb;
-        m.ss = sc < A.S ? sc : A.S - 1;
-        m.bb = b0 + ((sc < A.S && r < nb) ? r : nb - 1);
+        m.idle_wave = gw >= ns * nbp;
+        m.active = sc < ns && r < A.B;
+        m.ss = s0 + (sc < ns ? sc : ns - 1);
+        m.bb = m.active ? r : A.B - 1;
     } else {
         m.idle_wave = A.seq_begin + gw >= seq_hi;
         m.active = A.seq_begin + g < seq_hi;
         const int64_t lin = m.active ? A.seq_begin + g : seq_hi - 1;
-        m.bb = lin / A.S;
-        m.ss = lin - m.bb * A.S;
+        m.ss = lin / A.B;
+        m.bb = lin - m.ss * A.B;
     }
-    m.seq = m.bb * A.S + m.ss;
+    m.seq = m.ss * A.B + m.bb;
+    m.oseq = m.bb * A.S + m.ss;
     return m;
 }
 
@@ -1036,8 +1125,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     V a[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
+    const bool fold_seq = lane.try_fold();  // (float32: the folded model, see Lane::try_fold)
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank);
+    if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     // Do the four sequences of this wave read ONE observation row (true for every wave of a range of whole particles:
     // map_group), and are their hom emissions far enough from zero for the het / missing ratios to exist?  Then the codes are scalars and every run of sites is one
@@ -1045,7 +1135,22 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     bool uni = false;
     if constexpr (DENSE && PHK_DENSE_UNI != 0) {
         const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && lane.etab[0] > RATIO_MIN_EMIS0) != 0;
+        uni = __all((int)ss == ss0 && (fold_seq || lane.etab[0] > RATIO_MIN_EMIS0)) != 0;
+    }
+    // The other float32 layouts: sequences are stored chunk-major (SeqMap), so a wave holds the particles of ONE chunk,
+    // or of two where it crosses a chunk boundary.  Such a wave (uni2) folds its hom emission into the factors
+    // (Lane::fold_emissions) and takes its codes as scalars: a block of T sites that is hom in both rows -- 85 % of the
+    // blocks at 1 % hets -- runs without a single emission row (no LDS gather, no multiply: a timing-only build of the
+    // one-lane forward kernel without them ran cfg2's forward phase in 8.1 instead of 10.8 ms); any other block takes
+    // the straight-line path with per-lane codes as ever, its rows now the ratios emis1 / emis0, 1 / emis0 and 1.
+    constexpr bool FOLD = !DENSE && sizeof(real) == 4 && PHK_FWD_FOLD != 0;
+    bool uni2 = false, rowB = false;
+    if constexpr (FOLD) {
+        const int sA = __builtin_amdgcn_readfirstlane((int)ss), sB = __builtin_amdgcn_readlane((int)ss, 63);
+        // (a sequence folds whenever its own ratios exist, whatever its wave does: a site's row is then exactly 1 where
+        // the wave-uniform path would have skipped the multiply, so both paths return the same bits)
+        uni2 = __all(((int)ss == sA || (int)ss == sB) && fold_seq) != 0;
+        rowB = (int)ss != sA;
     }
 
     int E = 0;
@@ -1287,7 +1392,86 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         }
     };
     auto lean_piece = [&](const int b) { return b + BPC <= nfull && (blkW < b || blkW >= b + BPC); };
+    // (uni2 waves) T hom sites: the structured step alone
+    auto hom_block = [&]() {
+        V none[NP];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            real sc;
+            const int ex = lane.template fwd_site<false>(a, none, sc, rescale_after<NRM>(i));
+            E += ex;
+            if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
+#if PHK_FWD_SITE_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    // (uni2 waves) one lean piece: the codes of the wave's two rows (the same row twice in most waves) as scalars
+    auto fold_piece = [&](const uint64_t loA, const uint64_t hiA, const uint64_t loB, const uint64_t hiB) {
+        if constexpr (CKPT) {
+            if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
+                if (seg_left == 0) {
+                    if (active && rank == 0) *esp = E;
+                    esp += nseq;
+                    seg_left = A.seg_blocks;
+                }
+                seg_left -= BPC;
+            }
+        }
+        real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
+        int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
+#pragma nounroll
+        for (int hf = 0; hf < 2; ++hf) {
+            uint64_t wa = hf == 0 ? loA : hiA, wb = hf == 0 ? loB : hiB;
+#pragma nounroll
+            for (int bi = 0; bi < BPC / 2; ++bi) {
+                if constexpr (CKPT) {
+#if !PHK_EXP_NO_CKPT_STORE
+#pragma unroll
+                    for (int i = 0; i < SPL; ++i) ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)] = L::get(a, i);
+#endif
+                    ck_u += ck_step;
+                }
+                const int E0 = E;
+                const uint32_t ca = (uint32_t)wa & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
+                const uint32_t cb = (uint32_t)wb & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
+                if (__builtin_expect((ca | cb) == 0u, 1)) hom_block();
+                else straight_block(rowB ? cb : ca);
+                if constexpr (CKPT) {
+                    eb_u[sq_off_e] = (int16_t)(E - E0);
+                    eb_u += nseq;
+                    eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
+                }
+                wa >>= 2 * T;
+                wb >>= 2 * T;
+            }
+        }
+        blk += BPC;
+        if constexpr (CKPT) {
+            ckp += (int64_t)BPC * ck_step;
+            ebp += (int64_t)BPC * nseq;
+        }
+    };
     for (int pc = 0; blk < nblk; pc += PPB) {
+     if constexpr (LEAN && FOLD) {
+         // uni2 waves read both rows by scalar loads for as long as the pieces are lean (see the one-state-per-lane
+         // loop below: no wait for the checkpoint stores; each piece is landed before the next is requested)
+         if (uni2 && lean_ok && lean_piece(blk)) {
+             const ScalarPieces spA = scalar_pieces(pieces), spB = scalar_pieces_of_lane(pieces, 63);
+             PieceWords nA = spA[pc], nB = spB[pc];
+             do {
+                 PieceWords cA = nA, cB = nB;
+                 asm volatile("" : "+s"(cA.x), "+s"(cA.y), "+s"(cA.z), "+s"(cA.w), "+s"(cB.x), "+s"(cB.y), "+s"(cB.z), "+s"(cB.w) : : "memory");
+                 nA = spA[pc + 1 < npieces ? pc + 1 : npieces - 1];
+                 nB = spB[pc + 1 < npieces ? pc + 1 : npieces - 1];
+                 fold_piece((uint64_t)cA.x | ((uint64_t)cA.y << 32), (uint64_t)cA.z | ((uint64_t)cA.w << 32),
+                            (uint64_t)cB.x | ((uint64_t)cB.y << 32), (uint64_t)cB.z | ((uint64_t)cB.w << 32));
+                 ++pc;
+             } while (lean_piece(blk));
+             if (blk >= nblk) break;
+             pnext = pieces[pc < npieces ? pc : npieces - 1];
+         }
+     }
      if constexpr (LEAN && DENSE && PHK_DENSE_UNI != 0 && PHK_UNI_SLOAD != 0) {
          // Such a wave reads its observation words by SCALAR loads for as long as the pieces are lean: s_load counts
          // in lgkmcnt, so the wait for the piece requested ahead no longer drains the checkpoint stores (vmcnt counts
@@ -1460,7 +1644,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         (ex_slack < 0 || !(cend > 0.0)))
         atomicOr(A.risk, FLAG_UNDERFLOW);
     if (active && rank == 0) {
-        A.ll[seq] = log(cend) + (double)E * LN2 - llW;
+        A.ll[sm.oseq] = log(cend) + (double)E * LN2 - llW;  // (the caller's order: see SeqMap)
         if constexpr (CKPT) {
             A.aux[seq].inv_end = 1.0 / cend;
             A.aux[seq].e_end = E;
@@ -1490,17 +1674,30 @@ constexpr int bwd_waves_per_simd() {
 // the kernel over its 256-VGPR budget (two waves per SIMD), and the compiler's answer is scratch inside the block loop.
 // PARKED of the T vectors therefore live in LDS instead: explicit 16-byte stores in the beta pass, loads one site ahead in
 // the forward pass, in the thread's own slice behind its emission table (no barrier: nothing is shared).
+// Sweeps in the folded form (see bwd_kernel, SFOLD): the beta-first body in float32.  Their posterior-mass rows --
+// touched at het / missing sites only -- live in LDS behind the emission table, [3][EROW] reals indexed by the site's
+// code like the table itself.
 template <typename real, int K, int R, int T, int NRM>
-constexpr int sweep_parked() { return (PHK_SWEEP_V2 != 0 && PHK_PARK != 0 && NRM > 1 && T == 8 && (K / R) * (int)sizeof(real) == 32) ? PHK_PARK : 0; }
-// reals per thread of the backward kernel's LDS slice: emission table + parked vectors, the stride in 16-byte units odd
-// (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
+constexpr bool sweep_folds() { return PHK_SWEEP_FOLD != 0 && sizeof(real) == 4 && PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * (K / R) * (int)sizeof(real) <= 256; }
+#ifndef PHK_PARK_UNFOLDED
+#define PHK_PARK_UNFOLDED 3  // ... of the bodies that keep their emission rows (float64): round 3's figure
+#endif
+template <typename real, int K, int R, int T, int NRM>
+constexpr int sweep_parked() {
+    if (!(PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && (K / R) * (int)sizeof(real) == 32)) return 0;
+    return sweep_folds<real, K, R, T, NRM>() ? PHK_PARK : PHK_PARK_UNFOLDED;
+}
+// reals per thread of the backward kernel's LDS slice: emission table + mass rows + parked vectors, the stride in 16-byte
+// units odd (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
 template <typename real, int K, int R, int T, int NRM>
 constexpr int sweep_lds_stride() {
     using L = Lane<real, K, R>;
     constexpr int park = sweep_parked<real, K, R, T, NRM>() * 2 * L::NP;
-    if (park == 0) return L::ETAB_STRIDE;
+    constexpr int gtab = sweep_folds<real, K, R, T, NRM>() ? 3 * L::EROW : 0;
+    if (park + gtab == 0) return L::ETAB_STRIDE;
     constexpr int per16 = 16 / (int)sizeof(real);
-    int n = L::ETAB_STRIDE + park;
+    int n = L::ETAB_STRIDE + gtab + park;
+    n = (n + per16 - 1) / per16 * per16;
     if ((n / per16) % 2 == 0) n += per16;
     return n;
 }
@@ -1531,15 +1728,43 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     const bool active = gid < seq_hi;
     const int64_t seq = active ? gid : seq_hi - 1;
     const int rank = tid & (R - 1);
-    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+    const int64_t ss = seq / A.B, bb = seq - ss * A.B;  // chunk-major order (see SeqMap)
+    const int64_t oseq = bb * A.S + ss;                   // ... the caller's, for grad
 
     L lane;
     V pi[NP];
     const real* prm = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
     constexpr int PARKN = sweep_parked<real, K, R, T, NRM>();
+    constexpr bool SFOLD = sweep_folds<real, K, R, T, NRM>();
     real* etab = (real*)smem_raw + (size_t)tid * sweep_lds_stride<real, K, R, T, NRM>();
-    real* const park = etab + L::ETAB_STRIDE;  // (16-byte aligned: ETAB_STRIDE is a whole number of 16-byte units)
+    real* const gtab = etab + L::ETAB_STRIDE;                     // SFOLD: posterior-mass rows [3][EROW], by code
+    real* const park = gtab + (SFOLD ? 3 * L::EROW : 0);          // parked w vectors
     lane.load(prm, rank, etab, pi);
+    if constexpr (SFOLD) {
+#pragma unroll
+        for (int j = 0; j < 3 * L::EROW; ++j) gtab[j] = real(0);
+    }
+    // Folded form (kernels with the beta-first body: SFOLD).  The emission of a site multiplies the COLUMN index of A,
+    // the one b, d and v carry: with (b, d, v) <- emis0 .* (b, d, v) and the table rows 1, emis1 / emis0, 1 / emis0
+    // (Lane::fold_emissions) both recursions keep their form -- it is the same HMM written with hom emission 1 -- and
+    //   gb, gd, gv   accumulate the gradient w.r.t. the FOLDED factors (d/db_j = emis0_j d/db'_j, applied at the end),
+    //   gu           is unchanged (suf(v' .* w_hat) = suf(v .* w)),
+    //   the posterior mass p .* w of a site is booked at het and missing sites only (rows 1 and 2 of gtab), and the hom
+    //                row is the remainder: the mass summed over ALL sites is b' gb + d' gd + v' gv, state by state.
+    // A site that is hom in every lane of the wave -- with sequences stored chunk-major a wave reads one or two
+    // observation rows, so that is 96-98 % of the sites at 1 % hets -- then needs no emission row, no row .* beta, no
+    // row .* (A alpha) and no mass at all.  A sequence folds whenever its own ratios exist (Lane::emissions_foldable), so
+    // what is computed for it does not depend on its wave; one that cannot keeps its emissions in the table and books
+    // its hom mass in row 0, and its wave treats every site as "not hom" (the folded lanes then multiply by rows that are
+    // exactly 1: the same bits).  The flag goes to aux for the segment sweep's finalize.
+    // Kernels without that body (16-site blocks, per-site rescaling, 16 states per lane) run on the folded model all the
+    // same (Lane::try_fold) and book the hom mass directly; only the conversion at the end differs (aux.folded = 2).
+    const bool folded = lane.try_fold();  // (per sequence)
+    const int g0code = (SFOLD && folded) ? 2 : 0;
+    const bool wave_folded = SFOLD && __all(folded) != 0;
+    if constexpr (SEG) {
+        if (active && rank == 0 && blockIdx.y == 0) A.aux[seq].folded = folded ? (SFOLD ? 1 : 2) : 0;
+    }
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
     const real* ck = (const real*)A.ckpt;
 
@@ -1651,6 +1876,15 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     // fold the partial sums into float64 (units >= 1 of the segment sweep: store them, exactly once, at their left edge)
     auto flush = [&]() {
         since_flush = 0;
+        if constexpr (SFOLD) {  // the mass rows of the folded form live in LDS (see the hot body): row g0code and the het row
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                g0[h] = *(const V*)(gtab + g0code * L::EROW + 2 * h);
+                g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
+            }
+#pragma unroll
+            for (int j = 0; j < 3 * L::EROW; ++j) gtab[j] = real(0);
+        }
         if (active) {
 #pragma unroll
             for (int i = 0; i < SPL; ++i) {
@@ -1715,6 +1949,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #pragma unroll
                 for (int h = 0; h < NP; ++h) beta[h] = beta[h] * fx;
             }
+            V m0[NP], m1[NP];  // SFOLD: this block's mass rows (g0code and het), added to the LDS rows below
+#pragma unroll
+            for (int h = 0; h < NP; ++h) m0[h] = m1[h] = splat<real>(real(0));
 #pragma unroll
             for (int i = T - 1; i >= 0; --i) {
                 if (i < ns) {
@@ -1742,8 +1979,21 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                     const bool SC = rescale_after<NRM>(i);
                     V e[NP];
                     lane.emis((codes >> (2 * i)) & 3, e);
-                    lane.bwd_site(al[i], al[i + 1], beta, e, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC,
-                                  gb, gd, gu, gv, g0, g1);
+                    if constexpr (SFOLD)
+                        lane.bwd_site(al[i], al[i + 1], beta, e, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC,
+                                      gb, gd, gu, gv, m0, m1, g0code);
+                    else
+                        lane.bwd_site(al[i], al[i + 1], beta, e, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC,
+                                      gb, gd, gu, gv, g0, g1, g0code);
+                }
+            }
+            if constexpr (SFOLD) {
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    V* r0 = (V*)(gtab + g0code * L::EROW + 2 * h);
+                    V* r1 = (V*)(gtab + 1 * L::EROW + 2 * h);
+                    *r0 = *r0 + m0[h];
+                    *r1 = *r1 + m1[h];
                 }
             }
             if constexpr (F64ACC) {
@@ -1791,6 +2041,132 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                     // pass: the longest lifetimes), the others in registers
                     constexpr int NREG = T - PARKN;
                     V w[NREG > 0 ? NREG : 1][NP];
+                    if constexpr (SFOLD) {
+                        // Folded form: ONE body.  A site that is hom in every lane of the wave multiplies by no emission
+                        // row and books no posterior mass (its row is 1 and its mass is part of the remainder, see where
+                        // the wave folds its emissions); any other site does both behind a wave-uniform branch on one bit
+                        // of `nh`.  With sequences stored chunk-major a wave reads one or two observation rows, so at 1 %
+                        // hets 98 % of the sites take the fall-through.  (Round 4 compiled the hom block as a second
+                        // instance of the whole body: the allocator paid for the union of the two at their join, 712 ->
+                        // 964 B of scratch and reloads in the hot loop; the branches here enclose a few instructions each.)
+                        uint32_t nh = 0xffu;  // bit i: site i of the block is not hom in some lane (a wave with an unfolded sequence: every site)
+                        if (wave_folded) {
+                            const uint32_t m16 = ((codes | (codes >> 1)) & 0x5555u);  // this lane: bit 2i set = site i not hom
+                            nh = 0u;
+                            if (__builtin_expect(__any(m16 != 0u), 0)) {
+#pragma unroll
+                                for (int i = 0; i < T; ++i) nh |= __any((m16 >> (2 * i)) & 1u) ? (1u << i) : 0u;
+                            }
+                        }
+#pragma unroll
+                        for (int i = T - 1; i >= 0; --i) {
+                            V wi[NP];
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wi[h] = beta[h];
+                            if (__builtin_expect((nh >> i) & 1u, 0)) {
+                                V e[NP];
+                                lane.emis((codes >> (2 * i)) & 3, e);
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) wi[h] = beta[h] * e[h];
+                            }
+                            if (i >= NREG) {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) *(V*)(park + ((i - NREG) * NP + h) * 2) = wi[h];
+                            } else {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) w[i][h] = wi[h];
+                            }
+                            V svw[NP], pbw[NP], cb;
+                            lane.scans_adj(wi, svw, pbw, cb);
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) beta[h] = lane.beta_prev(h, wi, svw, pbw, cb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        V a[NP];
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) a[h] = al0[h];
+                        V wc[NP];  // w of the current site; a parked one is requested one site ahead
+                        if (NREG > 0) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wc[h] = w[0][h];
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wc[h] = *(const V*)(park + h * 2);
+                        }
+#pragma unroll
+                        for (int i = 0; i < T; ++i) {
+                            V wn[NP];
+                            if (i + 1 < T) {
+                                if (i + 1 >= NREG) {
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) wn[h] = *(const V*)(park + ((i + 1 - NREG) * NP + h) * 2);
+                                } else {
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) wn[h] = w[i + 1 < NREG ? i + 1 : 0][h];
+                                }
+                            }
+                            V pre[NP], suf[NP], svw[NP], t[NP];
+                            lane.scans(a, pre, suf);
+                            lane.suffix_vw(wc, svw);
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) {
+                                gd[h] = fma2<real>(wc[h], a[h], gd[h]);
+                                gb[h] = fma2<real>(wc[h], suf[h], gb[h]);
+                                gv[h] = fma2<real>(wc[h], pre[h], gv[h]);
+                                gu[h] = fma2<real>(a[h], svw[h], gu[h]);
+                                V tt = lane.d[h] * a[h];
+                                tt = fma2<real>(lane.v[h], pre[h], tt);
+                                t[h] = fma2<real>(lane.b[h], suf[h], tt);
+                            }
+                            // (the four rows are pinned here: left alone the compiler sinks their updates past the branch
+                            // below to the end of the block and keeps every site's scans in scratch until then)
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) asm volatile("" : "+v"(gd[h]), "+v"(gb[h]), "+v"(gv[h]), "+v"(gu[h]));
+                            if (__builtin_expect((nh >> i) & 1u, 0)) {
+                                // the site's posterior mass p .* w into the row of its code (a hom lane of a folded wave
+                                // adds to row 0, which nobody reads), then the emission row
+                                const int code = (codes >> (2 * i)) & 3;
+                                if constexpr (sizeof(real) == 4) {
+                                    // (pair by pair through two temporaries, opaque to the register allocator: written in
+                                    // C++ the sixteen registers of the two rows in flight made it spill the block's w
+                                    // vectors around every one of these branches)
+                                    uint32_t ea = lds_addr(etab + code * L::EROW), ga = lds_addr(gtab + code * L::EROW);
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) {
+                                        V te, tg;
+                                        asm volatile(
+                                            "ds_read_b64 %0, %3\n\t"
+                                            "ds_read_b64 %1, %4\n\t"
+                                            "s_waitcnt lgkmcnt(0)\n\t"
+                                            "v_pk_fma_f32 %1, %2, %5, %1\n\t"
+                                            "v_pk_mul_f32 %2, %2, %0\n\t"
+                                            "ds_write_b64 %4, %1\n\t"
+                                            "v_add_u32 %3, 8, %3\n\t"
+                                            "v_add_u32 %4, 8, %4"
+                                            : "=&v"(te), "=&v"(tg), "+v"(t[h]), "+v"(ea), "+v"(ga)
+                                            : "v"(wc[h])
+                                            : "memory");
+                                    }
+                                } else {
+                                    V* grow = (V*)(gtab + code * L::EROW);
+                                    const V* erow = (const V*)(etab + code * L::EROW);
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) {
+                                        grow[h] = fma2<real>(t[h], wc[h], grow[h]);
+                                        t[h] = t[h] * erow[h];
+                                    }
+                                }
+                            }
+                            if (i + 1 < T) {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) {
+                                    a[h] = t[h];
+                                    wc[h] = wn[h];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
                     V ec[NP];
                     lane.emis((codes >> (2 * (T - 1))) & 3, ec);
 #pragma unroll
@@ -1879,6 +2255,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    }
                 } else {
                     V al[T + 1][NP];
                     real sc[T / NRM];
@@ -1942,8 +2319,15 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         }
         return;  // grad_finalize_kernel turns gacc / bpi into the gradient
     }
+    if constexpr (SFOLD && !F64ACC) {  // (never flushed: the mass rows are still in LDS)
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            g0[h] = *(const V*)(gtab + g0code * L::EROW + 2 * h);
+            g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
+        }
+    }
     // d ll / d theta (or theta * that), rows b,d,u,v,emis0,emis1,pi
-    real* out = (real*)A.grad + seq * 7 * K + rank * SPL;
+    real* out = (real*)A.grad + oseq * 7 * K + rank * SPL;
     const bool dl = A.grad_dlog != 0;
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
@@ -1955,12 +2339,25 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
             vb = L::get(gb, i); vd = L::get(gd, i); vu = L::get(gu, i);
             vv = L::get(gv, i); v0 = L::get(g0, i); v1 = L::get(g1, i);
         }
+        if (folded) {  // folded form -> the caller's (see where the sequence folds its emissions)
+            const double e0 = (double)prm[4 * K + rank * SPL + i], e1 = (double)prm[5 * K + rank * SPL + i];
+            const double lb = vb * (double)L::get(lane.b, i), ld = vd * (double)L::get(lane.d, i), lv = vv * (double)L::get(lane.v, i);
+            // hom row: all sites - het sites - missing sites where the hot body booked those (SFOLD), else booked directly
+            const double mhom = SFOLD ? lb + ld + lv - v1 - v0 : v0;
+            out[0 * K + i] = (real)(dl ? lb : vb * e0);
+            out[1 * K + i] = (real)(dl ? ld : vd * e0);
+            out[2 * K + i] = (real)(dl ? vu * (double)L::get(lane.u, i) : vu);
+            out[3 * K + i] = (real)(dl ? lv : vv * e0);
+            out[4 * K + i] = (real)(dl ? mhom : mhom / e0);
+            out[5 * K + i] = (real)(dl ? v1 : v1 / e1);
+        } else {
         out[0 * K + i] = (real)(dl ? vb * (double)L::get(lane.b, i) : vb);
         out[1 * K + i] = (real)(dl ? vd * (double)L::get(lane.d, i) : vd);
         out[2 * K + i] = (real)(dl ? vu * (double)L::get(lane.u, i) : vu);
         out[3 * K + i] = (real)(dl ? vv * (double)L::get(lane.v, i) : vv);
         out[4 * K + i] = (real)(dl ? v0 : v0 / (double)etab[0 * L::EROW + L::SLOT(i)]);
         out[5 * K + i] = (real)(dl ? v1 : v1 / (double)etab[1 * L::EROW + L::SLOT(i)]);
+        }
         // pi is re-read here rather than kept in registers through the sweep (the kernel sits at its VGPR budget)
         out[6 * K + i] = (real)(dl ? (double)L::get(beta, i) * (double)prm[6 * K + rank * SPL + i] : (double)L::get(beta, i));
     }
@@ -1995,8 +2392,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     V pi[NP], beta[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
+    const bool fold_seq = lane.try_fold();  // (float32: the folded model, see Lane::try_fold)
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.template load_dense<true>(A.ops_b + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank);
+    if constexpr (DENSE) lane.template load_dense<true>(A.ops_b + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
 #pragma unroll
     for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
 #pragma unroll
@@ -2005,7 +2403,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     bool uni = false;  // the wave's sequences share their observation row and the emission ratios exist (see fwd_kernel)
     if constexpr (DENSE && PHK_DENSE_UNI_SCAN != 0) {
         const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && lane.etab[0] > RATIO_MIN_EMIS0) != 0;
+        uni = __all((int)ss == ss0 && (fold_seq || lane.etab[0] > RATIO_MIN_EMIS0)) != 0;
     }
     int F = 0;
     int f_slack = 1 << 20;  // dense kernel: smallest distance to its threshold of an exponent a rescale removed (see fwd_kernel: ex_slack)
@@ -2254,9 +2652,9 @@ __global__ void grad_finalize_kernel(KArgs A, int K, int units) {
     const int64_t sl = idx / (7 * K);
     const int rk = (int)(idx - sl * 7 * K);  // r * K + k
     const int64_t seq = A.seq_begin + sl;
-    const int64_t bb = seq / A.S, ss = seq - bb * A.S;
+    const int64_t ss = seq / A.B, bb = seq - ss * A.B;  // chunk-major order (see SeqMap); grad in the caller's
     const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
-    real* out = (real*)A.grad + seq * 7 * K;
+    real* out = (real*)A.grad + (bb * A.S + ss) * 7 * K;
     const bool dl = A.grad_dlog != 0;
     if (rk >= 6 * K) {  // the pi row
         const double bp = A.bpi[seq * K + (rk - 6 * K)];
@@ -2269,8 +2667,38 @@ __global__ void grad_finalize_kernel(KArgs A, int K, int units) {
         sum += (double)*pt;
         pt += nloc * 6 * K;
     }
-    if (rk < 4 * K) out[rk] = (real)(dl ? sum * (double)p[rk] : sum);
+    if (A.aux[seq].folded) out[rk] = (real)sum;  // sums of the folded form: grad_unfold_kernel converts them in place
+    else if (rk < 4 * K) out[rk] = (real)(dl ? sum * (double)p[rk] : sum);
     else out[rk] = (real)(dl ? sum : sum / (double)p[rk]);
+}
+
+// Segment sweep, folded form (see bwd_kernel): the six rows grad_finalize_kernel left as plain sums -> the caller's
+// gradient, one thread per (sequence, state).
+template <typename real>
+__global__ void grad_unfold_kernel(KArgs A, int K) {
+    const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (seq_hi - A.seq_begin) * K) return;
+    const int64_t seq = A.seq_begin + idx / K;
+    const int k = (int)(idx % K);
+    if (!A.aux[seq].folded) return;
+    const int64_t ss = seq / A.B, bb = seq - ss * A.B;
+    const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
+    real* out = (real*)A.grad + (bb * A.S + ss) * 7 * K;
+    const bool dl = A.grad_dlog != 0;
+    const double e0 = (double)p[4 * K + k], e1 = (double)p[5 * K + k];
+    const double vb = (double)out[0 * K + k], vd = (double)out[1 * K + k], vu = (double)out[2 * K + k], vv = (double)out[3 * K + k];
+    const double vm = (double)out[4 * K + k], v1 = (double)out[5 * K + k];
+    // folded factors exactly as the kernels formed them (float products)
+    const double lb = vb * (double)(p[0 * K + k] * p[4 * K + k]), ld = vd * (double)(p[1 * K + k] * p[4 * K + k]);
+    const double lv = vv * (double)(p[3 * K + k] * p[4 * K + k]);
+    const double mhom = A.aux[seq].folded == 1 ? lb + ld + lv - v1 - vm : vm;  // (2: the hom mass was booked directly)
+    out[0 * K + k] = (real)(dl ? lb : vb * e0);
+    out[1 * K + k] = (real)(dl ? ld : vd * e0);
+    out[2 * K + k] = (real)(dl ? vu * (double)p[2 * K + k] : vu);
+    out[3 * K + k] = (real)(dl ? lv : vv * e0);
+    out[4 * K + k] = (real)(dl ? mhom : mhom / e0);
+    out[5 * K + k] = (real)(dl ? v1 : v1 / e1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2300,8 +2728,15 @@ __global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict_
     const int64_t bb = q / S_blocks, ss = q - bb * S_blocks;
     const float* p = params + bb * pstride_b + ss * pstride_s;
     const int t = threadIdx.x, r = t >> 4, c = t & 15;
-    const double bc = p[0 * 16 + c], dc = p[1 * 16 + c], ur = p[2 * 16 + r], vc = p[3 * 16 + c], e0 = p[4 * 16 + c];
-    const double m = (r > c ? bc : (r == c ? dc : ur * vc)) * e0;
+    const double ur = p[2 * 16 + r];
+    // (from the factors as the structured steps of the same sequence use them: folded in float32 where the sequence
+    // folds -- Lane::try_fold -- so that dense and structured steps advance the same model)
+    const float e0f = p[4 * 16 + c];
+    const bool fold = PHK_FOLD != 0 && __syncthreads_and(e0f > RATIO_MIN_EMIS0);
+    const double bc = fold ? (double)(p[0 * 16 + c] * e0f) : (double)p[0 * 16 + c] * (double)e0f;
+    const double dc = fold ? (double)(p[1 * 16 + c] * e0f) : (double)p[1 * 16 + c] * (double)e0f;
+    const double vc = fold ? (double)(p[3 * 16 + c] * e0f) : (double)p[3 * 16 + c] * (double)e0f;
+    const double m = r > c ? bc : (r == c ? dc : ur * vc);
     float* of = ops_f + q * DENSE_OPS_FLOATS;
     float* ob = ops_b + q * DENSE_OPS_FLOATS;
     auto emit = [&](int n, double val) {

@@ -27,8 +27,11 @@ pytestmark = pytest.mark.gpu
 # Measured worst cases over every sample of this file (round 3): float32 ll 3.4e-7 (unrounded parameters: it IS the
 # rounding of the parameter block to float32) and 2.7e-8 (rounded parameters: kernel arithmetic alone); float64 ll
 # 1.7e-14; float32 gradient rows 1.4e-4 of their own maximum and of the whole-row maximum; float64 5.6e-14.
+# Round 5: the float32 kernels fold the hom emission into the factors (b, d, v) <- emis0 .* (b, d, v), one more rounding
+# per factor that is the same at every site: vs the oracle on rounded parameters 2.0e-7 .. 2.4e-7 over this file's samples
+# (profiles/r05_full_size_parity.txt), bar 6e-7; vs unrounded parameters 4.8e-7 at most, bar unchanged.
 F32_LL_BASELINE = 1e-5  # the bar BASELINE.json sets; asserted as well as the tighter ones below
-F32_LL_UNROUNDED, F32_LL_ROUNDED = 1.5e-6, 1.5e-7
+F32_LL_UNROUNDED, F32_LL_ROUNDED = 1.5e-6, 6e-7
 F64_LL = 1e-13
 F32_GRAD_A, F32_GRAD_C = 4e-4, 3e-4
 F64_GRAD_A, F64_GRAD_C = 2e-13, 2e-13
@@ -315,7 +318,7 @@ def test_cfg2_full_size_at_10pct_hets():
     sample on both sides of the split, gradient call == no-gradient call, the W = 0 identities over the whole batch."""
     eng = _full_size_case(16, 100, 500, 60_000, 500, het_rate=0.10, seed=5, static_plan=True)
     plan = eng.get_plan()
-    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16, plan
+    assert plan.get("hybrid_first") == 32700 and plan["R_scan"] == 16, plan
     assert not eng.underflow_risk()
 
 
@@ -385,18 +388,19 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     plan = eng.get_plan()
     assert plan.get("hybrid_first") == 32768 and plan["R_segment_sweep"] == 4
     # ... and with the one-state-per-lane (dense hom-run) beta scan, for which the library rounds the split down
-    # to whole particles (65 x 500) so that the four sequences of a scan wave share their chunk
+    # to whole chunks (327 x 100: sequences are stored chunk-major) so that the four sequences of a scan wave share
+    # their chunk
     monkeypatch.setenv("PHK_HYBRID", "2:1:32768:4:16")
     ll_d, g_d = eng.run(P, inds, W, grad=True)
     plan = eng.get_plan()
-    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16, plan
+    assert plan.get("hybrid_first") == 32700 and plan["R_scan"] == 16, plan
     monkeypatch.delenv("PHK_HYBRID")
     eng.set_autotune(True)
     eng.set_deterministic(True)  # the static rule picks exactly that plan for this shape
     ll_r, g_r = eng.run(P, inds, W, grad=True)
     plan = eng.get_plan()
     # (segment sweep by the serial sweep's own 8-states-per-lane kernel since round 3: phk_api.hip, static_plan)
-    assert plan.get("hybrid_first") == 32500 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 2, plan
+    assert plan.get("hybrid_first") == 32700 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 2, plan
     assert torch.equal(ll_r, ll_d)  # (same forward kernel; the gradients come from different segment-sweep variants)
     monkeypatch.setenv("PHK_HYBRID", "2:1:32768:2:16")
     eng.set_deterministic(False)
