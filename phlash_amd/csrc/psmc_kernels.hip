@@ -1392,15 +1392,31 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         }
     };
     auto lean_piece = [&](const int b) { return b + BPC <= nfull && (blkW < b || blkW >= b + BPC); };
-    // (uni2 waves) T hom sites: the structured step alone
-    auto hom_block = [&]() {
-        V none[NP];
+    // (uni2 waves) one full block: `ca` / `cb` are the codes of the wave's two rows as scalars.  Every site takes the
+    // structured step on the folded factors; a site that is not hom in one of the two rows multiplies by its row behind a
+    // wave-uniform branch on one bit (a folded lane's hom row is exactly 1, so the lanes of the other row lose nothing).
+    // At 1 % hets + 1 % missing 96-98 % of the sites take the fall-through: no LDS gather, no multiply.  (Round 4 chose
+    // per BLOCK between an emission-free body and the per-lane-code body: 72-85 % of the blocks.)
+    auto fold_block = [&](const uint32_t ca, const uint32_t cb) {
+        const uint32_t cu = ca | cb;
+        const uint32_t nhm = (cu | (cu >> 1)) & 0x55555555u;  // bit 2i: site i is not hom in one of the wave's rows
+        const uint32_t mine = rowB ? cb : ca;                   // this lane's codes
 #pragma unroll
         for (int i = 0; i < T; ++i) {
+            V none[NP];
             real sc;
-            const int ex = lane.template fwd_site<false>(a, none, sc, rescale_after<NRM>(i));
-            E += ex;
-            if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
+            lane.template fwd_site<false>(a, none, sc, false);
+            if (__builtin_expect((nhm >> (2 * i)) & 1u, 0)) {
+                V e[NP];
+                lane.emis((mine >> (2 * i)) & 3, e);
+#pragma unroll
+                for (int h = 0; h < NP; ++h) a[h] = a[h] * e[h];
+            }
+            if (rescale_after<NRM>(i)) {
+                const int ex = lane.rescale(a);
+                E += ex;
+                if (NRM > 1) ex_slack = min(ex_slack, ex - RISK_EXP);
+            }
 #if PHK_FWD_SITE_BARRIER
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1435,8 +1451,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 const int E0 = E;
                 const uint32_t ca = (uint32_t)wa & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
                 const uint32_t cb = (uint32_t)wb & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
-                if (__builtin_expect((ca | cb) == 0u, 1)) hom_block();
-                else straight_block(rowB ? cb : ca);
+                fold_block(ca, cb);
                 if constexpr (CKPT) {
                     eb_u[sq_off_e] = (int16_t)(E - E0);
                     eb_u += nseq;

@@ -143,3 +143,32 @@ def test_bench_plain_multi_gpu_form_fails_loudly_without_gpus():
     assert p.returncode != 0
     assert p.stdout.strip() == ""
     assert p.stderr.count("no HIP device visible") == 2 and "rank exit codes [1, 1]" in p.stderr
+
+
+def test_sweep_block_loops_stay_out_of_scratch():
+    """The throughput sweeps (8 float32 states per lane: K = 16 / 32 / 64 at R = 2 / 4 / 8) sit at their 256-register
+    budget; what the compiler spills must stay outside the loop over checkpoint blocks (round 3 split the hot blocks into
+    a loop of their own for that, round 5 pinned the gradient rows before the per-site branches of the folded body: left
+    alone the compiler sank their updates past the branches and kept every site's scans in scratch -- 170 scratch
+    accesses per block).  Read from the disassembly of the shipped objects: the block loop is the smallest loop that
+    holds the checkpoint prefetch (global loads) and at least 600 vector instructions, four in five of all it holds (the
+    general body's loops are half bookkeeping)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from loop_report import kernel_loops
+
+    checked = 0
+    for K, R in ((16, 2), (32, 4), (64, 8)):
+        obj = os.path.join(ROOT, "phlash_amd", "csrc", "build", f"launch_bwd_f32_{K}.o")
+        if not os.path.exists(obj):
+            pytest.skip("no build objects (the library was not built in this tree)")
+        for seg, allowed in ((0, 1), (1, 6)):  # serial sweep: the one reload DESIGN.md section 5 admits; segment sweep: <= 6 per block
+            ks = kernel_loops(obj, f"bwd_kernelIfLi{K}ELi{R}ELi8ELi4ELb{seg}E")
+            assert len(ks) == 1, list(ks)
+            loops = [r for r in next(iter(ks.values()))["loops"] if r["global"] >= 3 and r["valu"] >= 600 and r["valu"] >= 0.8 * r["n"]]
+            assert loops, "block loop not found"
+            blk = min(loops, key=lambda r: r["n"])
+            assert blk["n"] < 1500 and blk["scratch"] <= allowed, (K, R, seg, blk)
+            checked += 1
+    assert checked == 6
