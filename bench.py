@@ -88,6 +88,10 @@ def parse():
     ap.add_argument("--double", action="store_true", help="float64 kernels (default float32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-kernel", action="store_true", help="skip the reference-CUDA-kernel leg")
+    ap.add_argument("--extras-chunks", type=int, default=0, help="total chunk rows of the strong-scaling extra (tests that put "
+                    "several ranks on one GPU; default: cfg3's 5,000)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads timed after the headline loop "
+                    "(N = 1: the reference's production shape at 5 %% hets; N > 1: the cfg3 strong-scaling problem)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline leg")
     ap.add_argument("--pool-chunks", type=int, default=0, help="hold this many chunk rows and draw the step's --chunks rows from "
                     "them at random (with replacement, as fit() draws its minibatch: mcmc.py:277) instead of using the same rows every step")
@@ -293,6 +297,92 @@ def self_launch(n: int) -> int:
     return min(worst, 255)
 
 
+def extra_workload(name, rank, world, dev, local_rank, use_dist, steps, warmup, het_rate=None, double=False, chunks=0):
+    """A second workload timed in the same process AFTER the headline loop, with the same protocol (one discarded set-up
+    step, ``warmup`` untimed steps, ``steps`` timed steps between barriers, max over ranks, HIP-event kernel times): the
+    driver only ever runs the default command line, so what it should also see rides in its JSON line as an extra key --
+    ``value`` / ``config`` of the line stay the headline's.  Returns the dict to print (rank 0) or None."""
+    from phlash_amd import parallel, svgd
+    from phlash_amd import step as fused_step
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.synth import particle_population, simulate_chunks
+
+    cfg = CONFIGS[name]
+    K, B, S, L, W = cfg["K"], cfg["particles"], chunks or cfg["chunks"], cfg["chunk_size"], cfg["overlap"]
+    strong = cfg["scaling"] == "strong"
+    S_total = S if strong else world * S
+    if strong:
+        S = len(parallel.local_rows(S_total, rank, world))
+    if het_rate is not None:
+        g = np.random.default_rng(2000 + rank)
+        data = (g.random((S, W + L), dtype=np.float32) < het_rate).astype(np.int8)
+        data.flat[g.integers(0, data.size, size=int(0.01 * data.size))] = -1
+        data[:, 0] = np.maximum(data[:, 0], 0)
+        note = f"i.i.d. Bernoulli({het_rate:g}) hets + 1 % missing"
+    else:
+        data = simulate_chunks(K, S, W + L, seed=2000 + rank, theta=1e-2, rho=1e-2)
+        note = f"rows simulated from the default {K}-state HMM at theta = rho = 0.01 per window + 1 % missing"
+    afs = 1e5 / np.arange(1, cfg["afs_n"], dtype=np.float64) if cfg.get("afs_n") else None
+    template, x0 = particle_population(K, B, seed=1)
+    kern = get_kernel(K, data, double_precision=double, overlap=W, device=local_rank)
+    kern._eng.set_profiling(True)
+    inds = torch.arange(S, device=dev)
+    state = svgd.init(x0.to(dev))
+    flags = torch.zeros(2, dtype=torch.float64, device=dev)
+    assert fused_step.fusable(template, kern)
+
+    def one_step(st):
+        _, g = fused_step.log_density_and_grad(template, st.particles, (1.0, 1.0, 1.0), kern, inds, afs)
+        flags.add_(kern._flags)
+        return svgd.step(st, g, lr=0.1)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    one_step(state)  # set-up, discarded: the library tunes its plan for this shape
+    if use_dist and world > 1:
+        mine = kern._eng.get_plan()
+        keys = ("segmented", "R", "T", "R_forward", "R_scan", "hybrid_first", "R_segment_sweep")
+        pt = torch.tensor([int(mine.get(k, 0)) if rank == 0 else 0 for k in keys], dtype=torch.int64, device=dev)
+        dist.all_reduce(pt)
+        kern._eng.install_plan(dict(zip(keys, (int(v) for v in pt.cpu()))))
+    flags.zero_()
+    for _ in range(warmup):
+        state = one_step(state)
+    barrier()
+    kern._eng.timing_totals()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        state = one_step(state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fwd_ms, bwd_ms, _n = kern._eng.timing_totals()
+    plan = kern._eng.get_plan()
+    if use_dist and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ok = bool(torch.isfinite(state.particles).all()) and float(flags[0]) == 0 and float(flags[1]) == 0
+    del kern
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {
+        "workload": f"{name}: {cfg['what']} = {B} particles x {S} chunks x {L} scored sites (+{W} warm-up) on this rank, K={K}, "
+                    f"{'f64' if double else 'f32'}, {note}; the same full inner step as the headline",
+        "scaling": "strong" if strong else "weak",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "value": B * S_total * L * steps / elapsed,
+        "unit": "site·particle/s",
+        "kernel_ms": {"forward": fwd_ms / steps, "backward": bwd_ms / steps},
+        "plan": "segmented" if plan["segmented"] else ("hybrid" if plan.get("hybrid_first") else "serial"),
+        "checks_passed": ok,
+    }
+
+
 def main():
     a = parse()
     if "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus > 1:
@@ -480,6 +570,25 @@ def main():
             print(f"WARNING: ranks disagree on the particles after the timed loop (max difference "
                   f"{float((hi - lo).abs().max()):.3e})", file=sys.stderr, flush=True)
 
+    # how many ranks the RCCL communicator really joins: counted by the communicator itself (a SUM all-reduce of ones
+    # on the GPU), not read from WORLD_SIZE
+    rccl_ranks = 0
+    if use_dist and a.backend == "nccl":
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+    # extra workloads, same process, after the headline loop (all ranks take part; rank 0 keeps the dicts)
+    extras = {}
+    sized_as_config = all(getattr(a, k) == CONFIGS[a.config][k] for k in ("K", "particles", "chunks", "chunk_size", "overlap"))
+    if (not a.no_extras and a.config == "cfg2" and sized_as_config and not a.double and not a.variant and a.het_rate is None
+            and a.pool_chunks == 0 and not a.autograd_step):
+        if world == 1:
+            # the reference's default problem (mcmc.py:119-121, 193): 500 particles x minibatch of 5 x 100,000 windows
+            extras["secondary"] = extra_workload("prod", rank, world, dev, local_rank, use_dist, steps=50, warmup=5, het_rate=0.05)
+        else:
+            # north_star's multi-GPU config: the fixed 5,000-row problem sharded over the ranks
+            extras["strong_cfg3"] = extra_workload("cfg3", rank, world, dev, local_rank, use_dist, steps=5, warmup=1,
+                                                   chunks=a.extras_chunks)
     if rank == 0:
         work_per_step = B * S_total * L
         value = work_per_step * a.steps / elapsed
@@ -523,7 +632,7 @@ def main():
             **({"timing_only": "PHK_BENCH_TIMING_ONLY=1: result checks skipped, NOT a valid measurement of the shipped library"}
                if os.environ.get("PHK_BENCH_TIMING_ONLY") == "1" else {}),
             "backend": (a.backend if use_dist else None),
-            "rccl_ranks": (dist.get_world_size() if use_dist and a.backend == "nccl" else 0),
+            "rccl_ranks": rccl_ranks,
             "config": {
                 "workload": f"{a.what} = {S} chunks x {L} scored sites (+{W} warm-up) on this rank, "
                             f"K={K}, {B} SVGD particles; full inner step (param map, HIP fwd+bwd, "
@@ -592,6 +701,17 @@ def main():
                     }
             except Exception:
                 pass
+        for key, val in extras.items():
+            if val is not None:
+                out[key] = val
+        if "strong_cfg3" in out:  # against the N = 1 figure of the same problem measured on one GPU (static file)
+            try:
+                n1 = json.load(open(os.path.join(ROOT, "profiles", "scaling_expectation.json")))["bench_expectation"]["cfg3"]["N=1"]
+                out["strong_cfg3"]["speedup_vs_expectation_n1"] = out["strong_cfg3"]["value"] / n1["value"]
+                out["strong_cfg3"]["expectation_n1"] = {"ms_per_step": n1.get("ms_per_step"), "value": n1["value"],
+                                                        "source": "profiles/scaling_expectation.json"}
+            except Exception:
+                out["strong_cfg3"]["speedup_vs_expectation_n1"] = None
         if ranks_identical is not None:
             out["ranks_identical_after_timed_loop"] = ranks_identical
         if per_rank is not None:

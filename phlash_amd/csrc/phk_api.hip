@@ -53,12 +53,19 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 constexpr int DEFAULT_NRM = 4;   // rescale every 4th site unless told otherwise (measured: 1 -> 5.0e10, 2 -> 5.3e10, 4 -> 5.4e10; same parity)
-// sites per segment of the segmented backward: 512 (64 blocks at T = 8, 32 at T = 16).  PHK_SEG_SITES in the environment
-// (a multiple of 64, read once when the library is loaded) is a developer override for experiments
+// sites per segment of the segmented backward: 512 (64 blocks at T = 8, 32 at T = 16).  Builds with -DPHK_DEV_OVERRIDES
+// (experiments only) read PHK_SEG_SITES from the environment once, when the library is loaded, and say so on stderr; the
+// shipped library ignores the variable: a stray one must not change plans or the bits of a "deterministic" run.
 static int seg_sites_from_env() {
+#ifdef PHK_DEV_OVERRIDES
     const char* e = std::getenv("PHK_SEG_SITES");
     const int v = e ? std::atoi(e) : 0;
-    return (v >= 64 && v % 64 == 0 && v <= 65536) ? v : 512;
+    if (v >= 64 && v % 64 == 0 && v <= 65536) {
+        std::fprintf(stderr, "phk: developer override PHK_SEG_SITES=%d is active\n", v);
+        return v;
+    }
+#endif
+    return 512;
 }
 static const int SEG_SITES = seg_sites_from_env();
 inline int seg_blocks(int T) { return SEG_SITES / T; }
@@ -295,10 +302,13 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
 }
 
 Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
-    if (const char* env = std::getenv("PHK_HYBRID")) {  // developer override: "R:Rf:first:R3:R2"
+    if (const char* env = std::getenv("PHK_HYBRID")) {  // developer override: "R:Rf:first:R3:R2" (the plan is reported by phk_get_plan*)
         Plan p;
         long long first = 0;
         if (want_grad && std::sscanf(env, "%d:%d:%lld:%d:%d", &p.R, &p.R1, &first, &p.R3, &p.R2) == 5) {
+            static bool said = false;
+            if (!said) std::fprintf(stderr, "phk: developer override PHK_HYBRID=%s is active\n", env);
+            said = true;
             p.hybrid_first = first;
             return p;
         }
@@ -931,7 +941,7 @@ int phk_debug_copy_seeds(phk_handle* h, void* bseg_host, int64_t bseg_bytes, voi
 #endif
 
 int64_t phk_workspace_bytes(phk_handle* h) {
-    return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap + h->part.cap) : 0;
+    return h ? (int64_t)(h->ckpt.cap + h->aux.cap + h->gacc.cap + h->eblk.cap + h->eseg.cap + h->bseg.cap + h->fseg.cap + h->bpi.cap + h->part.cap + h->ops.cap) : 0;
 }
 
 int phk_set_profiling(phk_handle* h, int on) {
@@ -1173,6 +1183,10 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
     if (want_grad && !plan.segmented && plan.hybrid_first > 0 && !valid_Rs(h, plan.R3)) return fail(PHK_EINVAL, "segment sweep R=%d not available for K=%d", plan.R3, K);
     if (plan.segmented && (!valid_Rf(h, plan.R1) || !valid_Rf(h, plan.R2))) return fail(PHK_EINVAL, "invalid segmented plan for K=%d", K);
     if (!plan.segmented && plan.R1 != 0 && !valid_Rf(h, plan.R1)) return fail(PHK_EINVAL, "forward variant R=%d not available for K=%d", plan.R1, K);
+    if (plan_uses_dense(h, plan)) {  // sized before anything of this call is enqueued (growing it later would synchronise the device mid-step)
+        const int64_t blocks = std::min(Bs, B) * (pstride_s != 0 ? std::min(Ss, S) : 1);
+        if (int rc = h->ops.ensure((size_t)blocks * 2 * phk::DENSE_OPS_FLOATS * sizeof(float)); rc != PHK_OK) return rc;
+    }
     h->last_total = B * S;
     h->last_plan = plan;
     h->last_Bs = std::min(Bs, B);
@@ -1184,7 +1198,12 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
             const int64_t ns = std::min(Ss, S - s0);
             phk::KArgs a = make_args(b0, nb, s0, ns);
             if (plan_uses_dense(h, plan)) {
-                if (int rc = build_dense_ops(h, &a, st); rc != PHK_OK) return rc;
+                if (pstride_s == 0 && s0 > 0) {  // one block per particle: the table of this particle range is built already
+                    a.ops_f = (const float*)h->ops.p;
+                    a.ops_b = a.ops_f + nb * phk::DENSE_OPS_FLOATS;
+                } else if (int rc = build_dense_ops(h, &a, st); rc != PHK_OK) {
+                    return rc;
+                }
             }
             if (h->poison) {
                 // diagnostic (environment PHK_POISON=<byte>, e.g. 255 = NaN patterns): fill every scratch buffer with that byte before every

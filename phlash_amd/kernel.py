@@ -284,6 +284,12 @@ class PSMCKernel:
         return False
 
 
+    def switch_to_per_site_rescaling(self):
+        """What a positive underflow flag asks for (the reference's schedule, always safe), for callers that read the
+        reduced flags themselves."""
+        warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
+        self._eng.set_rescale_interval(1)
+
     def begin_check(self, also: torch.Tensor):
         """First half of ``check_rescaling(collective=True, also=...)``: queues the copy of the reduced flags and of
         ``also`` to pinned host memory on the current stream and returns at once, so that the caller can launch its

@@ -89,13 +89,8 @@ class _NoRows:
         assert bad == 0, "a chunk index was out of range on another rank"
         return under > 0
 
-    def begin_check(self, also):  # (the two halves of check_rescaling, as PSMCKernel has them)
-        flags, self._flags = self._flags, None
-        return flags, also
-
-    def finish_check(self, pending) -> bool:
-        self._flags, also = pending
-        return self.check_rescaling(collective=True, also=also)
+    def switch_to_per_site_rescaling(self):  # (no engine here: the ranks that own rows switch theirs)
+        pass
 
 
 def _join_process_group(device=None) -> int:
@@ -106,8 +101,11 @@ def _join_process_group(device=None) -> int:
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: phlash_amd.fit needs an MI355X (there is no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if device is not None:
-        torch.cuda.set_device(int(device))
+    if device is not None:  # an ordinal, "cuda:1" or a torch.device
+        device = device if isinstance(device, int) else torch.device(device).index
+        if device is None or not 0 <= device < torch.cuda.device_count():
+            raise ValueError(f"fit(device=...): no such HIP device among the {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(device)
     if dist.is_available() and dist.is_initialized():
         # The caller set the group up.  If it also chose a device (explicit device= option, one visible GPU
         # per rank, or it already moved off device 0) that choice stands.  A caller who only ran
@@ -131,7 +129,9 @@ def _join_process_group(device=None) -> int:
             raise RuntimeError("WORLD_SIZE > 1 but RANK is not set: launch with torchrun (one process per GPU)")
         local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
         ndev = torch.cuda.device_count()
-        if local >= ndev:
+        if device is not None:
+            local = device  # (the caller's choice stands here too)
+        elif local >= ndev:
             if ndev != 1:
                 raise RuntimeError(f"LOCAL_RANK={local} but only {ndev} HIP devices are visible to this process")
             local = 0  # the launcher bound one GPU per rank (HIP_VISIBLE_DEVICES): it is device 0 here
@@ -278,6 +278,26 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
                     k_, li = test_kern, np.arange(len(t_mine))
                 return _log_density_population(xs, template, c_elpd, k_, li, test_afs, afs_transform).mean(), k_
 
+        def elpd_local(xs):
+            """This rank's SHARE of the score and the flags of its evaluation, [3] float64 on the device, nothing
+            reduced: the speculative evaluation (below) adds the shares up later, on the sampler's own communicator.
+            The terms that do not depend on the rows (AFS, prior) are the same on every rank of chunk mode and count
+            on rank 0 only."""
+            with torch.no_grad():
+                tot = torch.zeros(3, dtype=F64, device=xs.device)
+                if by_particles:
+                    idx = torch.arange(rank, xs.shape[0], size, device=xs.device)
+                    if idx.numel():
+                        tot[0] = _log_density_population(xs[idx], template, c_elpd, test_kern, np.arange(N_test),
+                                                         test_afs, afs_transform, reduce=False).sum() / xs.shape[0]
+                    k_ = test_kern
+                else:
+                    c_mine = c_elpd if rank == 0 else c_elpd * torch.tensor([0.0, 1.0, 0.0], dtype=F64, device=dev)
+                    k_, li = (no_rows, np.zeros(0, np.int64)) if test_kern is None else (test_kern, np.arange(len(t_mine)))
+                    tot[0] = _log_density_population(xs, template, c_mine, k_, li, test_afs, afs_transform, reduce=False).mean()
+                k_.take_flags_into(tot[1:])
+                return tot, k_
+
         def elpd(xs):
             val, k_ = elpd_once(xs)
             # same decision on every rank (flags were all-reduced); the value comes back in the same copy
@@ -399,10 +419,13 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
     # (it must see every iteration once, in order) or ``speculative_elpd=False``.
     speculative = elpd is not None and cb is None and bool(options.get("speculative_elpd", True))
     elpd_stream = torch.cuda.Stream(dev) if speculative else None
-    # (its all-reduce waits for the whole evaluation: a communicator of its own, or the sampler's all-reduces, issued
-    # later, would queue behind it -- parallel.use_group.  Every rank creates the group here, in the same order.)
-    elpd_group = dist.new_group() if speculative and size > 1 else None
-    elpd_pending = None  # (iteration, state at that iteration, kernel object, flags + value on their way to the host)
+    # Its collective is NOT issued beside the sampler's: the evaluation leaves this rank's share and flags in a device
+    # buffer (elpd_local), and the shares are added up at collect time on the main stream through the sampler's own
+    # communicator -- ten iterations later, at the same iteration on every rank, in the same place of the launch order.
+    # (Round 4 all-reduced on the side stream through a communicator of its own: two RCCL kernels of one GPU spinning at
+    # the same time, which RCCL only tolerates while the device can co-schedule both -- ADVICE r04.)  With several ranks
+    # the sum of shares is the in-line value up to the rounding of one more addition per rank.
+    elpd_pending = None  # (iteration, state at that iteration, kernel object, (share buffer, event on the side stream))
 
     def judge_elpd(i0, e) -> bool:
         """The reference's early-stopping rule (mcmc.py:224-238) for the evaluation of iteration ``i0``."""
@@ -414,21 +437,27 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
 
     def launch_elpd(i0):
         elpd_stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(elpd_stream), parallel.use_group(elpd_group):
-            val, k_ = elpd_once(state.particles)
-            chk = k_.begin_check(also=val)
-        return i0, state, k_, chk
+        with torch.cuda.stream(elpd_stream):
+            tot, k_ = elpd_local(state.particles)
+            done = torch.cuda.Event()
+            done.record(elpd_stream)
+        return i0, state, k_, (tot, done)
 
     def collect_elpd() -> bool:
         """Reads the evaluation under way; True = the rule stops at ITS iteration: ``state`` goes back to that one."""
         nonlocal state, pending, elpd_pending
-        i0, st0, k_, chk = elpd_pending
+        i0, st0, k_, (tot, done) = elpd_pending
         elpd_pending = None
-        if k_.finish_check(chk):  # extreme particles: once more with per-site rescaling, at once
-            torch.cuda.current_stream(dev).wait_stream(elpd_stream)
+        torch.cuda.current_stream(dev).wait_event(done)  # (the buffer is written on the side stream)
+        parallel.all_reduce_sum_(tot)
+        e, under, bad = (float(v) for v in tot.cpu())  # synchronises; the same three numbers on every rank
+        k_._flags = None
+        assert bad == 0, "a chunk index of the held-out rows was out of range"
+        if under > 0:  # extreme particles: once more with per-site rescaling, at once and in line
+            k_.switch_to_per_site_rescaling()
             e = elpd(st0.particles)
-        else:
-            e = k_.also_value
+        elif not np.isfinite(e):
+            e = -float("inf")  # (model.py:71-73: a non-finite density counts as -inf)
         if judge_elpd(i0, e):
             pending = None  # (the unchecked step in flight belongs to the iterations that are dropped)
             state = st0

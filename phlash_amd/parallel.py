@@ -31,8 +31,6 @@ Chunk mode:
 
 from __future__ import annotations
 
-import contextlib
-
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -55,26 +53,13 @@ def split_minibatch(global_inds, rank: int, size: int) -> np.ndarray:
     return g[g % size == rank] // size
 
 
-_group = None  # the process group all_reduce_sum_ uses (None: the default group)
-
-
-@contextlib.contextmanager
-def use_group(group):
-    """Collectives issued inside go through ``group`` (a ``dist.new_group()``): a communicator of its own has a queue
-    of its own, so an all-reduce that waits for a long evaluation on a side stream (fit's held-out score) does not hold
-    back the sampler's all-reduces, which RCCL would otherwise run in issue order behind it."""
-    global _group
-    old, _group = _group, group
-    try:
-        yield
-    finally:
-        _group = old
-
-
 def all_reduce_sum_(buf: torch.Tensor) -> torch.Tensor:
-    """In-place SUM all-reduce of one fused buffer (no-op for a single process)."""
+    """In-place SUM all-reduce of one fused buffer (no-op for a single process).  Every collective of the package goes
+    through the default communicator, in program order, on the caller's current stream: RCCL tolerates two communicators
+    of one GPU working at the same time only while the device can co-schedule their kernels, so nothing here asks for it
+    (round 4's held-out score did, on a side stream; see mcmc.fit)."""
     if world()[1] > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_group)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 

@@ -12,6 +12,11 @@ scenario:
               rank 1 (which owns the odd rows) raises the underflow flag and rank 0's does not
   fake_flag   float32 kernels; rank (world - 1) reports an underflow flag at its first hand-over that
               the device never raised (particle mode has no data-driven way to flag one rank only)
+  early_stop  float64 kernels, ONE long held-out row (ranks >= 1 own none of it), elpd_cutoff = 5 and a held-out
+              score that is made to fall with every evaluation: the rule stops at the evaluation of iteration 10, which
+              runs beside the sampler and is read at iteration 20 -- every rank must read the same value, stop there
+              and roll back to the state of iteration 10 (ranks without held-out rows used to read the
+              buffer before the side stream had written it)
 Writes <out prefix>.rank<r>.pt: final models, the local flags this rank handed over (before the
 all-reduce), and the rescale intervals it switched to.
 """
@@ -115,17 +120,38 @@ def main():
         fstep.particle_params = extreme_blocks
 
     held_out = contigs("plain")[3] if scenario == "plain" else None
+    extra = {}
+    n_evals = []
+    if scenario == "early_stop":
+        from phlash_amd.data import RawContig
+
+        rng = np.random.default_rng(11)
+        long_row = (rng.uniform(size=200_000) < 0.05).astype(np.int8)  # ~4 ms per evaluation: longer than an iteration here
+        held_out = RawContig(het_matrix=long_row[None], afs=np.ones(1), window_size=100)
+        extra = dict(elpd_cutoff=5)
+        orig_lp = mcmc._log_density_population
+
+        def falling(x, template, c, kern, local_inds, afs, afs_transform, reduce=True):
+            lp = orig_lp(x, template, c, kern, local_inds, afs, afs_transform, reduce=reduce)
+            if float(c[0]) == 0.0:  # the held-out score (weights [0, 1, 1]): 1e6 lower with every evaluation, on rank 0's share
+                n_evals.append(1)
+                if rank == 0 or reduce:
+                    lp = lp - 1e6 * len(n_evals)
+            return lp
+
+        mcmc._log_density_population = falling
     try:
-        res = mcmc.fit(contigs(scenario), test_data=held_out, key=3, niter=12 if scenario == "plain" else 4, overlap=50,
+        res = mcmc.fit(contigs("plain" if scenario == "early_stop" else scenario), test_data=held_out, key=3,
+                       niter={"plain": 12, "early_stop": 40}.get(scenario, 4), overlap=50,
                        chunk_size=600, minibatch_size=4 if shard == "chunks" else 1, num_particles=6,
-                       double_precision=scenario == "plain", shard=shard, deterministic=True, progress=False,
-                       learning_rate=0.05)
+                       double_precision=scenario in ("plain", "early_stop"), shard=shard, deterministic=True, progress=False,
+                       learning_rate=0.05, **extra)
         torch.cuda.synchronize()
         torch.save({
             "c": torch.stack([r.eta.c for r in res]), "t": torch.stack([r.eta.t for r in res]),
             "rho": torch.tensor([r.rho for r in res], dtype=torch.float64),
             "handed": torch.stack(handed).cpu() if handed else torch.zeros(0, 2),
-            "nrm_calls": nrm_calls,
+            "nrm_calls": nrm_calls, "n_elpd_evals": len(n_evals),
         }, f"{out}.rank{rank}.pt")
     finally:
         if world > 1:

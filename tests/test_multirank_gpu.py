@@ -76,6 +76,23 @@ def test_two_ranks_reproduce_one(tmp_path, shard, scenario):
         assert two[0]["nrm_calls"] == two[1]["nrm_calls"] == []
 
 
+@pytest.mark.parametrize("shard", ["chunks", "particles"])
+def test_speculative_early_stop_is_taken_by_every_rank(tmp_path, shard):
+    """One long held-out row (rank 1 owns none of it in chunk mode), a score that falls with every evaluation and
+    elpd_cutoff = 5: the evaluation of iteration 10 runs beside the sampler, is read at iteration 20 and stops the run
+    there, rolling back to iteration 10.  Both ranks must return the particles of the single-process run and must have
+    evaluated the held-out score the same number of times (in line at 0, beside the sampler at 10 -- not at 20, 30)."""
+    one = _launch(1, str(tmp_path / "w1"), shard, "early_stop")[0]
+    two = _launch(2, str(tmp_path / "w2"), shard, "early_stop")
+    assert one["n_elpd_evals"] == 2, one["n_elpd_evals"]
+    for r in range(2):
+        assert two[r]["n_elpd_evals"] == 2, (r, two[r]["n_elpd_evals"])
+        for key in ("c", "t", "rho"):
+            np.testing.assert_allclose(two[r][key], one[key], rtol=2e-8, atol=1e-11, err_msg=f"rank {r} {key}")
+    for key in ("c", "t", "rho"):
+        assert torch.equal(two[0][key], two[1][key]), key  # the ranks agree to the bit
+
+
 def test_eight_ranks_reproduce_one(tmp_path):
     """World size 8 on the real kernels (gloo, all ranks on the one GPU): 8 chunk rows -> one row per rank, a
     minibatch of 4 rows -> ranks whose share of a minibatch is empty, one held-out row -> seven ranks without a
@@ -110,6 +127,21 @@ def test_bench_plain_form_self_launches_two_ranks():
     assert len(pr["plan"]) == 2 and len(set(pr["plan"])) == 1, pr  # rank 0's plan was installed on both
     assert len(pr["ms_per_step"]["all"]) == 2 and pr["ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
     assert 0 < line["config"]["het_rate"] < 0.2 and 0 < line["config"]["all_hom_word16_frac"] < 1
+
+
+def test_bench_default_command_at_two_ranks_carries_the_strong_scaling_extra():
+    """``python bench.py --gpus 2`` with the default (cfg2, weak scaling) sizes: after the headline loop the same launch
+    times the cfg3 strong-scaling problem (a fixed total of chunk rows sharded over the ranks, AFS n = 20) and prints it
+    as ``strong_cfg3``, leaving ``value`` the weak cfg2 figure.  Two ranks share the one GPU here (gloo), so the extra's
+    5,000 rows are cut to 64 (--extras-chunks); the headline runs at full size."""
+    line = _plain_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline",
+                         "--extras-chunks", "64"], timeout=1500)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["name"] == "cfg2"
+    assert line["value"] == pytest.approx(2 * 100 * 500 * 60000 / (line["ms_per_step"] * 1e-3), rel=1e-6)
+    ex = line["strong_cfg3"]
+    assert ex["scaling"] == "strong" and ex["n_gpus"] == 2 and ex["checks_passed"] is True
+    assert ex["value"] == pytest.approx(100 * 64 * 60000 / (ex["ms_per_step"] * 1e-3), rel=1e-6)
+    assert "speedup_vs_expectation_n1" in ex and line["rccl_ranks"] == 0  # (gloo: no RCCL communicator here)
 
 
 def test_bench_cfg3_eight_ranks_gloo_tiny():

@@ -79,34 +79,6 @@ def _worker_particles(rank, size, port, out):
         dist.destroy_process_group()
 
 
-def _worker_groups(rank, size, port, out):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=size)
-    try:
-        from phlash_amd import parallel
-
-        side = dist.new_group()
-        a = torch.full((3,), float(rank + 1), dtype=torch.float64)
-        b = torch.full((3,), float(10 * (rank + 1)), dtype=torch.float64)
-        with parallel.use_group(side):  # what fit() does for the held-out score: a communicator of its own
-            parallel.all_reduce_sum_(a)
-            assert parallel._group is side
-        assert parallel._group is None
-        parallel.all_reduce_sum_(b)  # ... and the default group afterwards
-        if rank == 0:
-            torch.save({"a": a, "b": b}, out)
-    finally:
-        dist.destroy_process_group()
-
-
-def test_all_reduce_through_a_group_of_its_own(tmp_path):
-    out = str(tmp_path / "g.pt")
-    mp.start_processes(_worker_groups, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
-    got = torch.load(out)
-    assert got["a"].tolist() == [3.0] * 3 and got["b"].tolist() == [30.0] * 3
-
-
 def test_particle_sharding(tmp_path):
     out = str(tmp_path / "p.pt")
     mp.start_processes(_worker_particles, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
