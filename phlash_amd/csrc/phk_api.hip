@@ -220,6 +220,12 @@ int largest_R(const phk_handle* h, int T) {
     return best;
 }
 
+int smallest_scan_R(const phk_handle* h) {  // fewest lanes per sequence (>= 2) a forward kernel / beta scan exists for
+    for (int c = 2; c <= 16; c <<= 1)
+        if (valid_Rf(h, c)) return c;
+    return 0;
+}
+
 int64_t n_units(const phk_handle* h, int T, int64_t W) {
     const int64_t nblk = (h->L + T - 1) / T;
     const int64_t nseg = (nblk + seg_blocks(T) - 1) / seg_blocks(T);
@@ -289,13 +295,18 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         if (p.R >= 2 && valid_Rf(h, p.R / 2) && nseq * (p.R / 2) / 64 >= 512) p.R1 = p.R / 2;
         const int64_t per_round = 1024 * (int64_t)(64 / p.R);
         const int64_t first = (nseq / per_round) * per_round;
-        if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, 4) &&
-            valid_T(h->K, 4, 8) && valid_Rf(h, 2)) {
+        // segment sweep: the serial sweep's own variant where that is the 8-states-per-lane float32 kernel (the folded
+        // beta-first body: fewest instructions per site, no scratch in its block loop), else 4 lanes per sequence;
+        // beta scan: the dense one-state-per-lane scan where it exists (K = 16), else the fewest lanes per sequence
+        // the state count allows (2 up to K = 32, 4 at K = 64: round 5 -- the rule used to ask for 2 and K = 64 never
+        // got a hybrid plan, 157 ms at cfg4 against the tuner's 146)
+        const int Rseg = (!h->dbl && h->K / p.R == 8 && valid_Rs(h, p.R)) ? p.R : 4;
+        const int Rscan = dense_scan_ok(h) ? 16 : smallest_scan_R(h);
+        if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, Rseg) &&
+            valid_T(h->K, Rseg, 8) && Rscan > 0) {
             p.hybrid_first = first;
-            // segment sweep: the serial sweep's own variant where that is the 8-states-per-lane float32 kernel (its
-            // block store partly in LDS: fewest instructions per site, no scratch), else 4 lanes per sequence
-            p.R3 = (!h->dbl && h->K / p.R == 8 && valid_Rs(h, p.R)) ? p.R : 4;
-            p.R2 = dense_scan_ok(h) ? 16 : 2;  // (16: see adjust_hybrid, applied once the launch shape is known)
+            p.R3 = Rseg;
+            p.R2 = Rscan;  // (16: see adjust_hybrid, applied once the launch shape is known)
         }
     }
     return p;
@@ -559,8 +570,18 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             float hbest = 0.f;
             // (segment sweep, beta scan) lanes per sequence; the static rule's choice first, and a later candidate
             // has to beat the best so far by 3 % (the candidates' single timings scatter by about 2 %)
-            const int cand[5][2] = {{2, 16}, {4, 16}, {2, 2}, {4, 2}, {4, 4}};
-            for (const auto& c : cand) {
+            // (the serial sweep's own variant first where it is the 8-states-per-lane kernel: K = 32 / 64 had no such
+            // candidate before round 5)
+            const int Rmin = smallest_scan_R(h);
+            std::vector<std::pair<int, int>> cand;
+            auto add = [&](int r3, int r2) {
+                if (r2 <= 0 || std::find(cand.begin(), cand.end(), std::make_pair(r3, r2)) != cand.end()) return;
+                cand.push_back({r3, r2});
+            };
+            if (K / best.R == 8) { add(best.R, 16); add(best.R, Rmin); }
+            add(2, 16); add(4, 16); add(2, Rmin); add(4, Rmin); add(4, 4);
+            for (const auto& cc : cand) {
+                const int c[2] = {cc.first, cc.second};
                 if (!valid_Rs(h, c[0]) || !valid_T(K, c[0], 8) || !valid_Rf(h, c[1])) continue;
                 if (c[1] == 16 && !dense_scan_ok(h)) continue;
                 Plan hyb = best;

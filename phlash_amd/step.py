@@ -14,7 +14,9 @@ instead of the same arithmetic spread over ~25 small torch launches (stack / cas
 hand-over / prior / autograd's backward graph: 0.3 ms of a 5.5 ms step at the reference's production shape,
 profiles/r03_ab_experiments.txt item 18c).  ``model.log_density`` / ``mcmc._log_density_population`` (autograd)
 stay as the definition this is tested against (tests/test_kernel_api.py).  The AFS term (n > 2 samples) is
-evaluated by its own small autograd graph and enters ``phk_chain_rule`` as ``extra_val`` / ``extra_grad``.
+evaluated by its own small autograd graph and enters ``phk_chain_rule`` as ``extra_val`` / ``extra_grad``.  It depends
+on the particles only, so it is issued on a side stream BEFORE the kernels and runs beside the forward kernel (round 4
+ran its ~60 small launches, 3 ms at n = 20, after the all-reduce: serial, and replicated on every rank).
 """
 
 from __future__ import annotations
@@ -29,6 +31,16 @@ from .params import MCMCParams
 from .util import get_pattern
 
 F64 = torch.float64
+
+_side_streams: dict = {}
+
+
+def _side_stream(dev: torch.device) -> torch.cuda.Stream:
+    """One side stream per device for work that only depends on the particles (the AFS term)."""
+    key = dev.index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(dev)
+    return _side_streams[key]
 
 
 def fusable(template: MCMCParams, kern) -> bool:
@@ -71,7 +83,26 @@ def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_i
     pat = get_pattern(template.pattern)
     K, P = pat.M, len(pat)
     assert D == P + 3 and fusable(template, kern)
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    main = torch.cuda.current_stream(dev)
+    stream = ctypes.c_void_p(main.cuda_stream)
+    # (host numbers; a device tensor works but costs a synchronisation)
+    c0, c1, c2 = (float(v) for v in (c.tolist() if isinstance(c, torch.Tensor) else c))
+    extra_val = extra_grad = afs_done = None
+    if afs is not None and len(afs) > 1:  # beside the kernels: see the module docstring
+        from .model import afs_term
+
+        side = _side_stream(dev)
+        side.wait_stream(main)  # (x may have been produced on the main stream a moment ago)
+        with torch.cuda.stream(side):
+            xa = x.detach().requires_grad_(True)
+            l3 = afs_term(template.from_flat(xa).to_dm(), afs, afs_transform)
+            (extra_grad,) = torch.autograd.grad(l3.sum(), xa)
+            extra_val, extra_grad = l3.detach().contiguous(), extra_grad.contiguous()
+            afs_done = torch.cuda.Event()
+            afs_done.record(side)
+        x.record_stream(side)
+        extra_val.record_stream(main)  # (allocated on the side stream, read by phk_chain_rule on the main one)
+        extra_grad.record_stream(main)
     _params, jac, p_kernel = particle_params(template, x, eng.double_precision)
     if isinstance(local_inds, torch.Tensor):
         inds = local_inds.to(device=dev, dtype=torch.int64)
@@ -87,16 +118,8 @@ def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_i
     kern._flags = buf[B, :2]  # where check_rescaling(collective=True) / begin_check read the (reduced) flags
     if reduce:
         parallel.all_reduce_sum_(buf)
-    # (host numbers; a device tensor works but costs a synchronisation)
-    c0, c1, c2 = (float(v) for v in (c.tolist() if isinstance(c, torch.Tensor) else c))
-    extra_val = extra_grad = None
-    if afs is not None and len(afs) > 1:
-        from .model import afs_term
-
-        xa = x.detach().requires_grad_(True)
-        l3 = afs_term(template.from_flat(xa).to_dm(), afs, afs_transform)
-        (extra_grad,) = torch.autograd.grad(l3.sum(), xa)
-        extra_val, extra_grad = l3.detach().contiguous(), extra_grad.contiguous()
+    if afs_done is not None:
+        main.wait_event(afs_done)
     logp = torch.empty(B, dtype=F64, device=dev)
     grad = torch.empty((B, D), dtype=F64, device=dev)
     _lib.check(lib.phk_chain_rule(dev.index, K, P, float(template.alpha), float(template.beta), x.data_ptr(),
