@@ -187,6 +187,40 @@ def test_hip_vs_live_reference_kernels_random_inputs(K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L", [4107, 20_000, 60_500])
+def test_f32_accuracy_on_nearly_empty_rows_next_to_the_reference_f32_kernels(L):
+    """The float32 accuracy limit, pinned where it shows ("float32 accuracy"): rows with hardly any het
+    site have |ll| of a few units however long they are, and what a float32 evaluation loses is NOT relative to |ll|: the
+    factors of the model are rounded to 2^-24 once and the same rounding acts at every site, so the error of ll grows
+    with the row length -- about 1e-8 per site here (an all-hom row and a row with one het per 2,000 sites).  The
+    reference's own float32 kernels, run live on the same rows, lose as much or more (their ll is a float32 sum of
+    per-site logs in the gradient kernel).  Bars: ours <= 3e-8 per site absolute (and 1e-5 relative wherever |ll| >=
+    3e-3 per site, the regime of BASELINE.json's rows); the reference's figure is printed beside ours."""
+    import torch
+
+    K = 16
+    if not refcuda.available(K, False):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    data = np.zeros((2, L), dtype=np.int8)
+    data[1, ::2000] = 1
+    P = np.stack([o.from_dm(o.default_dm("16*1", th, th)).stack() for th in (1e-2, 3e-3, 2e-2)])[:, None]  # [B = 3, 1, 7, K]
+    P32 = P.astype(np.float32).astype(np.float64)
+    PB = np.repeat(P32, 2, axis=1)
+    inds = np.arange(2)
+    ll_o = cport.batch(P32, data, inds, 0, grad=False)
+    ll_h = _engine(K, data, False).run(torch.tensor(P, device="cuda"), torch.tensor(inds, device="cuda"), 0, grad=False).cpu().numpy()
+    ll_hg, _ = _engine(K, data, False).run(torch.tensor(P, device="cuda"), torch.tensor(inds, device="cuda"), 0, grad=True)
+    ll_r32 = refcuda.call(K, False, data, inds, PB, grad=False)
+    ll_r32g, _, _ = refcuda.call(K, False, data, inds, PB, grad=True)
+    ours = max(np.abs(ll_h - ll_o).max(), np.abs(ll_hg.cpu().numpy() - ll_o).max())
+    ref = np.abs(ll_r32 - ll_o).max()
+    ref_g = np.abs(ll_r32g - ll_o).max()
+    print(f"PARITY nearly empty rows, L = {L}, |ll| {np.abs(ll_o).min():.2f} .. {np.abs(ll_o).max():.2f}: absolute error of ll, ours {ours:.2e} "
+          f"({ours / L:.1e} per site); reference float32 kernels: loglik {ref:.2e}, loglik_grad {ref_g:.2e}")
+    assert ours <= 3e-8 * L, (ours, L)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("het_rate", [0.05, 0.10])
 def test_hip_dense_het_runs_vs_live_reference_kernels(het_rate):
     """The production-shaped plan in small: 8 particles (two full waves per chunk, every wave on one observation row)
