@@ -1785,13 +1785,16 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 
     V beta[NP], gb[NP], gd[NP], gu[NP], gv[NP], g0[NP], g1[NP];
     const real inv_end = (real)A.aux[seq].inv_end;
-    const int64_t nblk = (A.Ltot + T - 1) / T;
+    // (block bookkeeping in 32-bit wave-uniform integers and stepped pointers, as in fwd_kernel: a block of the folded body
+    // is ~720 vector instructions, and 64-bit index products per block were 5 % of that and the segment sweep's last
+    // scratch accesses)
+    const int nblk = (int)((A.Ltot + T - 1) / T);
     // block range [blk_lo, blk_hi) of this unit
-    int64_t blk_lo = 0, blk_hi = nblk;
+    int blk_lo = 0, blk_hi = nblk;
     if constexpr (SEG) {
-        const int64_t G = A.seg_blocks;
-        const int64_t segW = A.W > 0 ? ((A.W - 1) / T) / G : 0;  // segment holding the warm-up boundary
-        const int64_t seg = segW + blockIdx.y;
+        const int G = A.seg_blocks;
+        const int segW = A.W > 0 ? (int)((A.W - 1) / T) / G : 0;  // segment holding the warm-up boundary
+        const int seg = segW + (int)blockIdx.y;
         blk_lo = blockIdx.y == 0 ? 0 : seg * G;
         blk_hi = (seg + 1) * G < nblk ? (seg + 1) * G : nblk;
     }
@@ -1817,7 +1820,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
             // factor on beta that does not decay along the sweep and shows up undamped in d ll/d pi
             // after the warm-up correction.  Normalise the seed against the forward kernel's own
             // alpha at this edge (its checkpoint): the identity then holds exactly where the sweep starts.
-            const real* ca = ck + blk_hi * nseq * K + L::ck_lane(nseq, seq, rank);
+            const real* ca = ck + (int64_t)blk_hi * nseq * K + L::ck_lane(nseq, seq, rank);
             real dot = real(0);
 #pragma unroll
             for (int i = 0; i < SPL; ++i) dot = fma_(ca[L::ck_elem(i, nseq)], L::get(beta, i), dot);
@@ -1841,14 +1844,20 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 
     real anext[SPL];
     // observation words, one word ahead of the (descending) block that needs it
-    int64_t widx = -1;
+    int widx = -1;
     uint32_t wcur = 0, wprev = 0;
     int e_next = 0;  // block exponent, requested one block ahead like the checkpoint (the beta-first body needs it first thing)
+    const int64_t ck_step = nseq * K;
+    const real* ckq = ck + L::ck_lane(nseq, seq, rank);  // this lane's piece of the checkpoint that is requested NEXT
+    const int16_t* ebq = A.eblk + seq;                   // ... and its block exponent
     if (blk_hi > blk_lo) {
-        const real* src = ck + (blk_hi - 1) * nseq * K + L::ck_lane(nseq, seq, rank);
+        ckq += (int64_t)(blk_hi - 1) * ck_step;
+        ebq += (int64_t)(blk_hi - 1) * nseq;
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) anext[i] = src[L::ck_elem(i, nseq)];
-        e_next = A.eblk[(blk_hi - 1) * nseq + seq];
+        for (int i = 0; i < SPL; ++i) anext[i] = ckq[L::ck_elem(i, nseq)];
+        e_next = *ebq;
+        ckq -= ck_step;
+        ebq -= nseq;
 
         widx = ((blk_hi - 1) * T) >> 4;
         wcur = words[widx];
@@ -1864,12 +1873,12 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     constexpr bool HOT_V2 = PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * SPL * (int)sizeof(real) <= 256;
     constexpr bool HOT_SL = !HOT_V2 && bwd_straight_line<real, K, R, T>() && bwd_waves_per_simd<real, K, R, T, SEG>() <= 2;
     constexpr bool HOT = HOT_V2 || HOT_SL;
-    const int64_t blkW = A.W > 0 ? (A.W - 1) / T : -1;                 // block holding the warm-up boundary
-    const int64_t blk_part = (A.Ltot % T) != 0 ? nblk - 1 : -1;      // partial block (the row's last), if any
+    const int blkW = A.W > 0 ? (int)((A.W - 1) / T) : -1;          // block holding the warm-up boundary
+    const int blk_part = (A.Ltot % T) != 0 ? nblk - 1 : -1;      // partial block (the row's last), if any
     // block prologue: step the observation words, take the block's checkpoint (requested one block earlier) and
     // request the next one, fetch the exponent total the forward kernel took out of the block
-    auto enter = [&](const int64_t blk, V (&al0)[NP], int& e_fwd, uint32_t& codes) {
-        const int64_t t0 = blk * T;
+    auto enter = [&](const int blk, V (&al0)[NP], int& e_fwd, uint32_t& codes) {
+        const int t0 = blk * T;  // (site index inside the row: < 2^31)
         if ((t0 >> 4) != widx) {  // stepped into the previous word
             widx = t0 >> 4;
             wcur = wprev;
@@ -1881,12 +1890,13 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         for (int i = 0; i < SPL; ++i) L::set(al0, i, anext[i]);
         e_fwd = e_next;
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint and exponent under this block's arithmetic
-            const real* src = ck + (blk - 1) * nseq * K + L::ck_lane(nseq, seq, rank);
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) anext[i] = src[L::ck_elem(i, nseq)];
-            e_next = A.eblk[(blk - 1) * nseq + seq];
+            for (int i = 0; i < SPL; ++i) anext[i] = ckq[L::ck_elem(i, nseq)];
+            e_next = *ebq;
+            ckq -= ck_step;
+            ebq -= nseq;
         }
-        codes = wcur >> (2 * (int)(t0 & 15));
+        codes = wcur >> (2 * (t0 & 15));
     };
     // fold the partial sums into float64 (units >= 1 of the segment sweep: store them, exactly once, at their left edge)
     auto flush = [&]() {
@@ -1937,10 +1947,10 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #else
     const bool wave_steep = HOT_V2 && __any(A.aux[seq].eb_min < HOT_MIN_EXP);
 #endif
-    int64_t blk = blk_hi - 1;
+    int blk = blk_hi - 1;
     while (blk >= blk_lo) {
         if (!HOT || wave_steep || blk == blkW || blk == blk_part) {
-            const int64_t t0 = blk * T;
+            const int64_t t0 = (int64_t)blk * T;
             V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
             real sc[T / NRM];
             int e_fwd, e_run = 0;  // exponent total of the block: forward kernel's, and the re-run's below
@@ -2020,15 +2030,15 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         }
         if constexpr (HOT) {
             // a run of hot blocks: down to the unit's left edge, the warm-up block or the next fold, whichever comes first
-            int64_t stop = blk_lo;
+            int stop = blk_lo;
             if (blkW >= blk_lo && blkW < blk) stop = blkW + 1;
             if constexpr (F64ACC) {
                 if (part == nullptr) {
-                    const int64_t left = since_flush < FLUSH_SITES ? (FLUSH_SITES - since_flush + T - 1) / T : 1;
+                    const int left = since_flush < FLUSH_SITES ? (FLUSH_SITES - since_flush + T - 1) / T : 1;
                     if (blk - left + 1 > stop) stop = blk - left + 1;
                 }
             }
-            const int64_t first = blk;
+            const int first = blk;
             for (; blk >= stop; --blk) {
                 int e_fwd;
                 uint32_t codes;

@@ -6,7 +6,7 @@ mkdir -p "$OUT"
 for r in $(seq 1 $ROUNDS); do
   for t in "$@"; do
     if [ "$t" = base ]; then unset PHK_LIB; else export PHK_LIB=$PWD/phlash_amd/csrc/exp/libphk_$t.so; fi
-    python bench.py --no-cpu-baseline $ARGS > "$OUT/${t}_$r.json" 2> "$OUT/${t}_$r.err"
+    python bench.py --no-cpu-baseline --no-extras $ARGS > "$OUT/${t}_$r.json" 2> "$OUT/${t}_$r.err"
     python - "$OUT/${t}_$r.json" "$t" "$r" <<'PY'
 import json, sys
 try:

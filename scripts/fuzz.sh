@@ -4,9 +4,9 @@
 # anywhere, missing runs, workspace slabs) and prints the distribution lines the bars in that file were derived from.
 #   scripts/fuzz.sh [seeds of the general test = 2000] [seeds of the dense-kernel test = 1500] [out dir = gpurun_out/fuzz]
 N1=${1:-2000}; N2=${2:-1500}; OUT=${3:-gpurun_out/fuzz}; mkdir -p "$OUT"
-PHK_FUZZ_SEEDS=$N1 python3 -m pytest tests/test_hip_parity.py -q -m gpu -s -k test_random_shapes_against_the_oracle > "$OUT/general.log" 2>&1
+PHK_FUZZ_SEEDS=$N1 python3 -m pytest tests/test_hip_parity.py -q -m gpu -s --timeout 120 -k test_random_shapes_against_the_oracle > "$OUT/general.log" 2>&1
 echo "general: $(tail -n 1 "$OUT/general.log")"
-PHK_DENSE_FUZZ_SEEDS=$N2 python3 -m pytest tests/test_hip_parity.py -q -m gpu -s -k test_dense_kernels_random_shapes > "$OUT/dense.log" 2>&1
+PHK_DENSE_FUZZ_SEEDS=$N2 python3 -m pytest tests/test_hip_parity.py -q -m gpu -s --timeout 120 -k test_dense_kernels_random_shapes > "$OUT/dense.log" 2>&1
 echo "dense:   $(tail -n 1 "$OUT/dense.log")"
 python3 - "$OUT/general.log" <<'PY'
 import re, sys

@@ -12,7 +12,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-reference-kernel --no-extras $*"  # (the headline loop only: under --pmc every dispatch of the extras and their tuner costs a counter read-out)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 RC=$?

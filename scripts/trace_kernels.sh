@@ -4,7 +4,7 @@
 OUT=$PWD/$1; shift
 REPO=$PWD
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline "$@" > "$OUT/run.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-extras "$@" > "$OUT/run.log" 2>&1
 cd "$REPO"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

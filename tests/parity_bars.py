@@ -31,6 +31,7 @@ def grad_error_ratios(g, g_ref, g_full, P, a, c):
         gf = np.array(g_full, dtype=np.float64)
         gf[..., 6, :] *= pi
         full = np.abs(gf).max(-1, keepdims=True)
+        full[..., 4, :] = np.maximum(full[..., 4, :], full[..., 5, :])
     err = np.abs(g - g_ref).max(-1, keepdims=True)
     r_bound = float((err / (a * own + c * full + 1e-300)).max())
     r_own = float((err / np.maximum(own, 1e-300)).max())

@@ -483,7 +483,9 @@ def test_random_shapes_against_the_oracle(seed):
         os.environ.pop("PHK_HYBRID", None)
     Pin = P if dbl else P.astype(np.float32).astype(np.float64)
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
-    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5, atol=1e-10 if dbl else 1e-5)
+    # (float32: 1e-5 relative, and never less than 1e-7 per site absolute -- the folded factors' rounding acts at every
+    # site, INTEGRATION.md 2d: typically 1e-8 per site, 2-5e-8 on a handful of 3,000 draws: seeds 464, 1422, 1504, 2473, 2746)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-10 if dbl else 1e-5, atol=1e-10 if dbl else max(1e-5, 1e-7 * L))
     # Gradient metric: per row (b, s, parameter row) the largest absolute error against
     #     bound = a * max|row of the oracle's gradient| + c * max|same row of the W = 0 gradient|.
     # (1) pi row in the form the reference kernel returns, pi_i * d ll/d pi_i (gpu.py:303-313): on data far
@@ -506,6 +508,7 @@ def test_random_shapes_against_the_oracle(seed):
         _, g_full = cport.batch(Pin, data, inds, 0)
         g_full[..., 6, :] *= P[..., 6, :]
         full = np.abs(g_full).max(axis=-1, keepdims=True)
+        full[..., 4, :] = np.maximum(full[..., 4, :], full[..., 5, :])  # (as `own`: the remainder's noise is eps x ALL the mass)
     err_row = np.abs(g - g_ref).max(axis=-1, keepdims=True)
     a, c = (F64_GRAD_OWN, F64_GRAD_FULL) if dbl else (F32_GRAD_OWN, F32_GRAD_FULL)
     bound = a * own + c * full + 1e-300
@@ -546,6 +549,7 @@ def _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, dbl):
         _, g_full = cport.batch(Pin, data, inds, 0)
         g_full[..., 6, :] *= P[..., 6, :]
         full = np.abs(g_full).max(axis=-1, keepdims=True)
+        full[..., 4, :] = np.maximum(full[..., 4, :], full[..., 5, :])
     err_row = np.abs(g - g_ref).max(axis=-1, keepdims=True)
     a, c = (F64_GRAD_OWN, F64_GRAD_FULL) if dbl else (F32_GRAD_OWN, F32_GRAD_FULL)
     return float((err_row / (a * own + c * full + 1e-300)).max())
@@ -591,8 +595,8 @@ def test_dense_kernels_random_shapes(seed):
         eng.set_plan(1, R=4, T=T, R_forward=16, R_scan=16)
     elif B * S >= 2:
         first = int(rng.integers(1, B * S))
-        if B >= 2 and rng.integers(2):  # a split between whole particles: the dense beta scan is kept (else: R = 2)
-            first = S * int(rng.integers(1, B))
+        if S >= 2 and rng.integers(2):  # a split between whole chunks (sequences are stored chunk-major): the dense beta scan is kept (else: R = 2)
+            first = B * int(rng.integers(1, S))
         hybrid = f"{int(rng.choice([2, 4, 16]))}:16:{first}:4:16"
     else:
         eng.set_plan(1, R=2, T=8, R_forward=16, R_scan=16)
@@ -607,8 +611,9 @@ def test_dense_kernels_random_shapes(seed):
     if slabbed and B * S > 1:
         assert slab[0] * slab[1] < B * S, slab
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
-    np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=1e-5)
+    atol = max(1e-5, 1e-7 * L)  # (1e-5 relative, never less than 1e-7 per site: INTEGRATION.md 2d)
+    np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=atol)
+    np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=atol)
     worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
     print(f"dense fuzz seed={seed} B={B} S={S} L={L} W={W} het={het} T={T} form={form} hybrid={hybrid} slab={slab}: "
           f"err/bound {worst:.2f}")
