@@ -539,13 +539,25 @@ int autotune(phk_handle* h, const Launchers& l, const phk::KArgs& proto, bool wa
             }
         }
         if (want_grad) {
-            for (int R = 1; R <= 16; R <<= 1) {
+            float bms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // sweep variants R = 1, 2, 4, 8, 16
+            for (int R = 1, ri = 0; R <= 16; R <<= 1, ++ri) {
                 if (!valid_Rb(h, R) || !valid_T(K, R, T)) continue;
                 float ms = 0.f;
                 if (!h->dbl) HIP_TRY(hipMemsetAsync(h->gacc.p, 0, (size_t)nseq * 6 * K * sizeof(double), st));
                 if ((rc = time_launch([&] { return l.bwd(R, T, h->nrm, at, 0, 256, st); }, &ms)) != PHK_OK) return rc;
                 if (verbose) std::fprintf(stderr, "phk tune: nseq %lld sweep   R=%d T=%d on %lld sites: %.3f ms\n", (long long)nseq, R, T, (long long)tune_sites, ms);
+                bms[ri] = ms;
                 if (!bb || ms < tb) { tb = ms; bb = R; }
+            }
+            // near-ties go to fewer lanes per sequence here too: at K = 64 the 8- and the 4-states-per-lane sweeps time
+            // 4.10 and 4.14 ms on the tuner's 2,048 sites, on a slow box the other way round, and at full length the
+            // first is 15 % faster (cfg4: 149 against 168 ms per step, profiles/r05_ab_experiments.txt item 11)
+            for (int R = 1, ri = 0; R < bb; R <<= 1, ++ri) {
+                if (bms[ri] > 0.f && bms[ri] <= 1.08f * tb) {
+                    bb = R;
+                    tb = bms[ri];
+                    break;
+                }
             }
         } else {
             bb = bf;
