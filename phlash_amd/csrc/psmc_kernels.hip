@@ -1890,6 +1890,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         for (int i = 0; i < SPL; ++i) L::set(al0, i, anext[i]);
         e_fwd = e_next;
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint and exponent under this block's arithmetic
+                             // (two blocks ahead: +2 ms at cfg2, profiles/r05_ab_experiments.txt item 13)
 #pragma unroll
             for (int i = 0; i < SPL; ++i) anext[i] = ckq[L::ck_elem(i, nseq)];
             e_next = *ebq;
