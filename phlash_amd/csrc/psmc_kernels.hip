@@ -98,12 +98,6 @@ __device__ __forceinline__ int frexp_exp_(double x) { return __builtin_amdgcn_fr
 __device__ __forceinline__ float ldexp_(float x, int e) { return __builtin_ldexpf(x, e); }
 __device__ __forceinline__ double ldexp_(double x, int e) { return __builtin_ldexp(x, e); }
 
-// byte offset of an LDS location inside the workgroup's allocation (what ds_* instructions take as their address)
-template <typename T>
-__device__ __forceinline__ uint32_t lds_addr(const T* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) T*)p;
-}
-
 // DPP move with zero fill for lanes whose source is outside the 16-lane row.
 // BANKS: 4-bit mask over the four 4-lane banks of a row; lanes of a disabled bank also get zero.
 template <int CTRL, int BANKS = 0xf>
@@ -2152,35 +2146,16 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                                 // the site's posterior mass p .* w into the row of its code (a hom lane of a folded wave
                                 // adds to row 0, which nobody reads), then the emission row
                                 const int code = (codes >> (2 * i)) & 3;
-                                if constexpr (sizeof(real) == 4) {
-                                    // (pair by pair through two temporaries, opaque to the register allocator: written in
-                                    // C++ the sixteen registers of the two rows in flight made it spill the block's w
-                                    // vectors around every one of these branches)
-                                    uint32_t ea = lds_addr(etab + code * L::EROW), ga = lds_addr(gtab + code * L::EROW);
+                                // (plain C++ since the gradient rows are pinned above: both rows are requested at once; round 5
+                                // first wrote this pair by pair in inline asm, suspecting the sixteen registers of the two rows
+                                // in flight of the spills that were the compiler's sinking -- 0.8 ms slower at 10 % hets)
+                                real* grow = gtab + code * L::EROW;
+                                const V* erow = (const V*)(etab + code * L::EROW);
 #pragma unroll
-                                    for (int h = 0; h < NP; ++h) {
-                                        V te, tg;
-                                        asm volatile(
-                                            "ds_read_b64 %0, %3\n\t"
-                                            "ds_read_b64 %1, %4\n\t"
-                                            "s_waitcnt lgkmcnt(0)\n\t"
-                                            "v_pk_fma_f32 %1, %2, %5, %1\n\t"
-                                            "v_pk_mul_f32 %2, %2, %0\n\t"
-                                            "ds_write_b64 %4, %1\n\t"
-                                            "v_add_u32 %3, 8, %3\n\t"
-                                            "v_add_u32 %4, 8, %4"
-                                            : "=&v"(te), "=&v"(tg), "+v"(t[h]), "+v"(ea), "+v"(ga)
-                                            : "v"(wc[h])
-                                            : "memory");
-                                    }
-                                } else {
-                                    V* grow = (V*)(gtab + code * L::EROW);
-                                    const V* erow = (const V*)(etab + code * L::EROW);
-#pragma unroll
-                                    for (int h = 0; h < NP; ++h) {
-                                        grow[h] = fma2<real>(t[h], wc[h], grow[h]);
-                                        t[h] = t[h] * erow[h];
-                                    }
+                                for (int h = 0; h < NP; ++h) {
+                                    V* gr = (V*)(grow + 2 * h);
+                                    *gr = fma2<real>(t[h], wc[h], *gr);
+                                    t[h] = t[h] * erow[h];
                                 }
                             }
                             if (i + 1 < T) {
