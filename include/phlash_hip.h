@@ -113,6 +113,18 @@ int phk_chain_rule(int device, int K, int P, double alpha, double beta, const do
                    const double* jac, int64_t B, double c_prior, double c_hmm, const double* extra_val,
                    const double* extra_grad, double c_extra, double* logp, double* grad, void* stream);
 
+/* The AFS term of the objective with its gradient w.r.t. the particles, one launch.  Replaces, under vmap + jax.grad,
+ *   l3 = xlogy(T afs, T esfs).sum(),  esfs = etbl / etbl.sum(),  etbl = W etjj          (src/phlash/model.py:58-68,
+ *   size_history.py:212-226: etjj_k = int_0^inf exp(-k(k-1)/2 R(t)) dt, k = 2..n, through JaxPPoly.exp_integral,
+ *   jax_ppoly.py:44-84; W = _W_matrix(n), size_history.py:350-369),
+ * a function of the particle through t = [0, geomspace(t1, tM, K-1)] and c = softplus(c_tr) by epoch only (params.py:94-127).
+ *   x      device [B, P+3];  n: sample size (n - 1 spectrum entries), 3 <= n <= 128 (n = 2: the term is 0, do not call)
+ *   tw     device [m, n-1] = T W,  w1 device [n-1] = column sums of W,  y device [m] = T afs   (constants of a run;
+ *          T = identity, m = n - 1, when the run has no afs_transform)
+ *   value  device [B];  grad device [B, P+3]: the arguments extra_val / extra_grad of phk_chain_rule */
+int phk_afs_term(int device, int K, int P, const int32_t* epoch_of_state, const double* x, int64_t B, int n, int m,
+                 const double* tw, const double* w1, const double* y, double* value, double* grad, void* stream);
+
 /* log_prior of the whole population with its gradient, one launch.  Replaces log_prior
  * (src/phlash/model.py:11-21) under vmap + jax.grad:
  *   value[b] = logN(log(rho/theta); 0, 1) - alpha * sum_i (log c_{i+1} - log c_i)^2 - beta * |x_b|^2

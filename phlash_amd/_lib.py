@@ -32,6 +32,7 @@ SIGNATURES = {
     "phk_chain_rule": (_i, [_i, _i, _i, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_double,
                             _vp, _vp, ctypes.c_double, _vp, _vp, _vp]),
     "phk_log_prior": (_i, [_i, _i, ctypes.c_double, ctypes.c_double, _vp, _i64, _vp, _vp, _vp]),
+    "phk_afs_term": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int32), _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "phk_svgd_workspace_doubles": (_i64, [_i64]),
     "phk_svgd_step": (_i, [_i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                            ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),

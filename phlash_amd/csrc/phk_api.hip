@@ -1063,6 +1063,37 @@ int phk_log_prior(int device, int P, double alpha, double beta, const double* x,
     return PHK_OK;
 }
 
+int phk_afs_term(int device, int K, int P, const int32_t* epoch_of_state, const double* x, int64_t B, int n, int m,
+                 const double* tw, const double* w1, const double* y, double* value, double* grad, void* stream) {
+    if (K < 3 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [3, %d]", K, phk::PM_MAXK);
+    if (P < 1 || P > K) return fail(PHK_EINVAL, "P=%d epochs for K=%d states", P, K);
+    if (n < 3 || n > phk::AF_MAXN) return fail(PHK_EUNSUPPORTED, "n=%d samples outside [3, %d] (n = 2 has no AFS term: model.py:58-68 gives 0)", n, phk::AF_MAXN);
+    if (m < 1 || m > phk::AF_MAXN) return fail(PHK_EUNSUPPORTED, "m=%d transform rows outside [1, %d]", m, phk::AF_MAXN);
+    if (!epoch_of_state || !x || !tw || !w1 || !y || !value || !grad) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0) return fail(PHK_EINVAL, "B must be >= 0");
+    phk::AFArgs a;
+    a.K = K;
+    a.P = P;
+    a.D = P + 3;
+    for (int k = 0; k < K; ++k) {
+        if (epoch_of_state[k] < 0 || epoch_of_state[k] >= P) return fail(PHK_EINVAL, "epoch_of_state[%d] = %d outside [0, %d)", k, epoch_of_state[k], P);
+        a.epoch[k] = (int8_t)epoch_of_state[k];
+    }
+    a.n1 = n - 1;
+    a.m = m;
+    a.x = x;
+    a.tw = tw;
+    a.w1 = w1;
+    a.y = y;
+    a.value = value;
+    a.grad = grad;
+    a.B = B;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_afs_term(a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "afs_term kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
 int phk_reduce_chunks(phk_handle* h, const double* ll, const void* grad, int64_t B, int64_t S, double* buf, void* stream) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (!ll || !grad || !buf) return fail(PHK_EINVAL, "NULL argument");

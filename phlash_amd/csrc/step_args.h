@@ -38,6 +38,23 @@ struct CRArgs {
 };
 hipError_t launch_chain_rule(const CRArgs& a, int64_t B, hipStream_t st);
 
+// the AFS term of the objective (param_map.hip): value and gradient w.r.t. the particle, one launch
+constexpr int AF_MAXN = 128;   // sample size n <= this (n - 1 expected branch lengths)
+struct AFArgs {
+    int K, P, D;
+    int8_t epoch[PM_MAXK];
+    int n1;               // n - 1
+    int m;                // rows of the transform T
+    const double* x;      // [B, D]
+    const double* tw;     // [m, n1] = T W   (W: Polanski-Kimmel matrix of size_history.py:350-369)
+    const double* w1;     // [n1] = column sums of W
+    const double* y;      // [m] = T afs
+    double* value;        // [B]
+    double* grad;         // [B, D]
+    int64_t B;
+};
+hipError_t launch_afs_term(const AFArgs& a, hipStream_t st);
+
 constexpr int SV_MAXD = 72;    // P + 3 <= 67
 constexpr int SV_MAXB = 4096;  // particles (the kernel row of one particle lives in LDS)
 

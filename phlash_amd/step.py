@@ -13,10 +13,10 @@ model.py:24-73, params.py:33-127, transition.py:37-85) is here
 instead of the same arithmetic spread over ~25 small torch launches (stack / cast / sum / buffer assembly / flag
 hand-over / prior / autograd's backward graph: 0.3 ms of a 5.5 ms step at the reference's production shape,
 profiles/r03_ab_experiments.txt item 18c).  ``model.log_density`` / ``mcmc._log_density_population`` (autograd)
-stay as the definition this is tested against (tests/test_kernel_api.py).  The AFS term (n > 2 samples) is
-evaluated by its own small autograd graph and enters ``phk_chain_rule`` as ``extra_val`` / ``extra_grad``.  It depends
-on the particles only, so it is issued on a side stream BEFORE the kernels and runs beside the forward kernel (round 4
-ran its ~60 small launches, 3 ms at n = 20, after the all-reduce: serial, and replicated on every rank).
+stay as the definition this is tested against (tests/test_kernel_api.py).  The AFS term (n > 2 samples) is one more
+HIP launch, ``phk_afs_term`` (value and gradient w.r.t. the particles by forward-mode duals, microseconds), issued right
+after the parameter map; it enters ``phk_chain_rule`` as ``extra_val`` / ``extra_grad``.  (Round 4 evaluated it by a torch
+autograd graph of ~60 small launches, 3 ms at n = 20, after the all-reduce: serial, and replicated on every rank.)
 """
 
 from __future__ import annotations
@@ -32,15 +32,47 @@ from .util import get_pattern
 
 F64 = torch.float64
 
-_side_streams: dict = {}
+_afs_consts: dict = {}
 
 
-def _side_stream(dev: torch.device) -> torch.cuda.Stream:
-    """One side stream per device for work that only depends on the particles (the AFS term)."""
-    key = dev.index
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(dev)
-    return _side_streams[key]
+def _afs_constants(afs, afs_transform, dev: torch.device):
+    """(n, m, T W [m, n-1], 1^T W [n-1], T afs [m]) on the device for one (spectrum, transform) pair: what
+    ``phk_afs_term`` needs of them (model.py:58-68 with etbl = W etjj, size_history.py:224-226), prepared once."""
+    afs = np.ascontiguousarray(np.asarray(afs, dtype=np.float64))
+    T = None if afs_transform is None else np.ascontiguousarray(np.asarray(afs_transform, dtype=np.float64))
+    key = (afs.tobytes(), None if T is None else (T.shape, T.tobytes()), dev.index)
+    if key not in _afs_consts:
+        from .size_history import _W_matrix
+
+        n = afs.shape[0] + 1
+        W = _W_matrix(n)
+        if T is None:
+            T = np.eye(n - 1)
+        assert T.ndim == 2 and T.shape[1] == n - 1
+        if len(_afs_consts) > 8:
+            _afs_consts.clear()
+        _afs_consts[key] = (n, T.shape[0], torch.as_tensor(T @ W, dtype=F64, device=dev).contiguous(),
+                            torch.as_tensor(W.sum(0), dtype=F64, device=dev).contiguous(),
+                            torch.as_tensor(T @ afs, dtype=F64, device=dev).contiguous())
+    return _afs_consts[key]
+
+
+def afs_term_and_grad(template: MCMCParams, x: torch.Tensor, afs, afs_transform=None):
+    """(l3 [B], d l3 / d x [B, D]) of the AFS term for particles x [B, D] float64 on the GPU, one HIP launch on the current
+    stream (``phk_afs_term``).  The autograd definition it is tested against: ``model.afs_term``."""
+    dev = x.device
+    B, D = x.shape
+    pat = get_pattern(template.pattern)
+    K, P = pat.M, len(pat)
+    assert D == P + 3
+    n, m, tw, w1, y = _afs_constants(afs, afs_transform, dev)
+    epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
+    val = torch.empty(B, dtype=F64, device=dev)
+    grad = torch.empty((B, D), dtype=F64, device=dev)
+    _lib.check(_lib.load().phk_afs_term(dev.index, K, P, epoch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), x.data_ptr(), B,
+                                        n, m, tw.data_ptr(), w1.data_ptr(), y.data_ptr(), val.data_ptr(), grad.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return val, grad
 
 
 def fusable(template: MCMCParams, kern) -> bool:
@@ -87,22 +119,9 @@ def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_i
     stream = ctypes.c_void_p(main.cuda_stream)
     # (host numbers; a device tensor works but costs a synchronisation)
     c0, c1, c2 = (float(v) for v in (c.tolist() if isinstance(c, torch.Tensor) else c))
-    extra_val = extra_grad = afs_done = None
-    if afs is not None and len(afs) > 1:  # beside the kernels: see the module docstring
-        from .model import afs_term
-
-        side = _side_stream(dev)
-        side.wait_stream(main)  # (x may have been produced on the main stream a moment ago)
-        with torch.cuda.stream(side):
-            xa = x.detach().requires_grad_(True)
-            l3 = afs_term(template.from_flat(xa).to_dm(), afs, afs_transform)
-            (extra_grad,) = torch.autograd.grad(l3.sum(), xa)
-            extra_val, extra_grad = l3.detach().contiguous(), extra_grad.contiguous()
-            afs_done = torch.cuda.Event()
-            afs_done.record(side)
-        x.record_stream(side)
-        extra_val.record_stream(main)  # (allocated on the side stream, read by phk_chain_rule on the main one)
-        extra_grad.record_stream(main)
+    extra_val = extra_grad = None
+    if afs is not None and len(afs) > 1:  # (n = 2: esfs = [1] and the term is exactly 0, model.py:58-68)
+        extra_val, extra_grad = afs_term_and_grad(template, x, afs, afs_transform)
     _params, jac, p_kernel = particle_params(template, x, eng.double_precision)
     if isinstance(local_inds, torch.Tensor):
         inds = local_inds.to(device=dev, dtype=torch.int64)
@@ -118,8 +137,6 @@ def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_i
     kern._flags = buf[B, :2]  # where check_rescaling(collective=True) / begin_check read the (reduced) flags
     if reduce:
         parallel.all_reduce_sum_(buf)
-    if afs_done is not None:
-        main.wait_event(afs_done)
     logp = torch.empty(B, dtype=F64, device=dev)
     grad = torch.empty((B, D), dtype=F64, device=dev)
     _lib.check(lib.phk_chain_rule(dev.index, K, P, float(template.alpha), float(template.beta), x.data_ptr(),

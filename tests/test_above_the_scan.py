@@ -414,3 +414,36 @@ def test_svgd_step_beyond_the_hip_limits_equals_the_loop_oracle():
         svgd.step_hip = orig
     assert not called  # the HIP path was not taken
     assert svgd.step(svgd.init(torch.zeros((4097, 3), dtype=torch.float64, device="cuda")), torch.zeros((4097, 3), dtype=torch.float64, device="cuda"), 0.1).particles.shape == (4097, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,n,transformed", [(16, 20, False), (16, 20, True), (32, 5, False), (64, 12, True)])
+def test_phk_afs_term_against_oracle_and_autograd(K, n, transformed):
+    """``phk_afs_term`` (one HIP launch: value and gradient of the AFS term w.r.t. the particles, what the fused step
+    runs) through ctypes: values against the lineage-chain oracle (``oracle/afs_numpy.py``, no W matrix), values and the
+    whole gradient against the autograd definition ``model.afs_term`` (itself held against the oracle and finite
+    differences above), with and without an afs_transform (fold + Bhaskar-Wang-Song binning, afs.py)."""
+    from phlash_amd.afs import bws_transform, fold_transform
+    from phlash_amd.model import afs_term
+    from phlash_amd.params import MCMCParams
+    from phlash_amd.step import afs_term_and_grad
+
+    pat, P, X = _population(K, 6, seed=31 + n)
+    afs = 1e5 / np.arange(1, n, dtype=np.float64) * (1.0 + 0.1 * np.cos(np.arange(n - 1)))
+    T = None
+    if transformed:
+        T1 = fold_transform(n)
+        T = bws_transform(T1 @ afs) @ T1
+    init = MCMCParams.from_linear(pat, 1e-4, 15.0, np.ones(P), 1e-2, 2e-2)
+    xs = torch.tensor(X, device="cuda", requires_grad=True)
+    want = afs_term(init.from_flat(xs).to_dm(), afs, T)
+    (gwant,) = torch.autograd.grad(want.sum(), xs)
+    val, g = afs_term_and_grad(init, xs.detach(), afs, T)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(val.cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-12)
+    scale = gwant.abs().max(dim=1, keepdim=True).values
+    assert float(((g - gwant).abs() / scale).max()) < 1e-10
+    assert float(g[:, -1].abs().max()) == 0.0  # rho does not enter
+    for b in range(X.shape[0]):
+        d = o.particle_to_dm(X[b], pat, 1e-2)
+        np.testing.assert_allclose(float(val[b]), oafs.afs_term(d.t, d.c, afs, T), rtol=1e-10)
