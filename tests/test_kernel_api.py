@@ -167,6 +167,12 @@ def test_functional2():
     res = phlash_amd.fit([ctg], niter=2, num_particles=5, chunk_size=1, overlap=1, progress=False)
     assert isinstance(res, list) and len(res) == 5
     assert isinstance(res[0], DemographicModel)
+    # the extension option device= takes an ordinal, a "cuda:i" string or a torch.device ...
+    for dev in (0, "cuda:0", torch.device("cuda", 0)):
+        assert len(phlash_amd.fit([ctg], niter=1, num_particles=3, chunk_size=1, overlap=1, progress=False, device=dev)) == 3
+    # ... and refuses one that does not exist instead of silently running elsewhere
+    with pytest.raises(ValueError):
+        phlash_amd.fit([ctg], niter=1, num_particles=3, chunk_size=1, overlap=1, progress=False, device=torch.cuda.device_count())
 
 
 def test_psmc(psmcfa_file):
