@@ -447,7 +447,7 @@ def test_cfg4_k64_rows_against_independent_dense_forward():
         for j, s in enumerate(rows):
             want[b, j] = (o.psmc_ll_dense(A, pp.emis0, pp.emis1, pp.pi, data[s])
                           - o.psmc_ll_dense(A, pp.emis0, pp.emis1, pp.pi, data[s, :W]))
-    for dbl, bar in ((True, 1e-13), (False, 6e-7)):  # measured 1.7e-14 / 1.05e-7
+    for dbl, bar in ((True, 1e-13), (False, 6e-7)):  # measured 1.7e-14 / 2.6e-7 (round 4, unfolded: 1.05e-7)
         eng = HipEngine(K, data, double_precision=dbl)
         ll, _ = eng.run(P, inds, W, grad=True)
         ll0 = eng.run(P, inds, W, grad=False)
