@@ -521,7 +521,10 @@ def test_random_shapes_against_the_oracle(seed):
     ll_only = _run(eng, P, inds, W, grad=False)
     # (two float32 evaluations by different kernel variants, each held to 1e-5 against the oracle above: they may differ
     # by twice that -- seed 1422 of the round-4 soak: 2.6e-6 and 1.03e-5 from the oracle, 1.2e-5 apart)
-    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else 2e-5)
+    # (... and per site like every float32 ll bar: dense operator steps and structured steps round the folded model
+    # differently but each the same way at every site -- seed 12579 of the round-5 soak: 2,600 all-hom sites, |ll| = 1.1,
+    # the two calls 2.3e-5 = 9e-9 per site apart, both inside their oracle bar)
+    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else max(2e-5, 2e-8 * L))
 
 
 def _runs_data(rng, n, L, het=0.02, miss_runs=3):
