@@ -135,6 +135,39 @@ def test_grad_ll_equals_nograd_ll(missing_data, pp):
 
 
 @pytest.mark.parametrize("W", [0, 41])
+def test_folded_model_is_the_same_hmm(data, W):
+    """The algebra the float32 kernels run on since round 5 ("Folded model"), checked in float64 with
+    the oracle alone: (b, d, v) <- emis0 .* (b, d, v) with emissions (1, emis1 / emis0) gives the same log-likelihood, and
+    the gradient of the folded model converts back as  d/db = emis0 .* d/db'  (same for d, v),  d/du unchanged,
+    emis1 .* d/d emis1 = r1 .* d/d r1  and  emis0 .* d/d emis0 = b' g_b' + d' g_d' + v' g_v' - r1 g_r1  -- the hom row
+    as the remainder of the total posterior mass.  (Rows without missing sites: the oracle's missing emission is 1 by
+    definition, where the kernels' folded table holds 1 / emis0.)"""
+    rng = np.random.default_rng(4)
+    dm = o.default_dm("16*1", theta=1e-2, rho=1e-2)
+    dm = dm._replace(c=dm.c * np.exp(0.4 * rng.normal(size=16)))
+    P = o.from_dm(dm).stack()  # rows b, d, u, v, emis0, emis1, pi
+    e0, e1 = P[4], P[5]
+    F = P.copy()
+    F[0], F[1], F[3] = P[0] * e0, P[1] * e0, P[3] * e0
+    F[4], F[5] = 1.0, e1 / e0
+    rows = data[:4, :300]
+    inds = np.arange(4)
+    ll, g = cport.batch(P[None, None], rows, inds, W)
+    llf, gf = cport.batch(F[None, None], rows, inds, W)
+    np.testing.assert_allclose(llf, ll, rtol=1e-12)
+    g, gf = g[0], gf[0]  # [4 chunks, 7, K]
+    scale = np.abs(g).max(axis=-1, keepdims=True)
+    back = gf.copy()
+    back[:, 0], back[:, 1], back[:, 3] = gf[:, 0] * e0, gf[:, 1] * e0, gf[:, 3] * e0
+    back[:, 5] = gf[:, 5] / e0
+    back[:, 4] = (F[0] * gf[:, 0] + F[1] * gf[:, 1] + F[3] * gf[:, 3] - F[5] * gf[:, 5]) / e0
+    np.testing.assert_allclose(back / scale, g / scale, atol=1e-11)
+    # ... and the identity the remainder rests on: total posterior mass = b' g_b' + d' g_d' + v' g_v', state by state
+    mass = P[4] * g[:, 4] + P[5] * g[:, 5]
+    np.testing.assert_allclose(F[0] * gf[:, 0] + F[1] * gf[:, 1] + F[3] * gf[:, 3], mass, rtol=1e-9, atol=1e-9 * np.abs(mass).max())
+
+
+@pytest.mark.parametrize("W", [0, 41])
 def test_reverse_mode_vs_autograd(missing_data, pp, W):
     d = missing_data[3][:250]
     ll_np, g_np = o.psmc_ll_grad(pp, d, W)
