@@ -1048,6 +1048,30 @@ __device__ __forceinline__ ScalarPieces scalar_pieces_of_lane(const uint4* p, co
     return (ScalarPieces)(((uint64_t)hi << 32) | lo);
 }
 
+// The checkpoint stream is written once and read once 10-20 ms later, 24 GB at cfg2: non-temporal stores (the `nt` bit: no
+// allocation in the caches on the way out).  What the stores cost the forward kernel at all: 1.1 of its 9.0 ms at cfg2 (a
+// timing-only build without them, profiles/r05_ab_experiments.txt item 16) -- back-pressure of a 2.7 TB/s write stream, not
+// instructions; nt takes 0.13 ms of that back, non-temporal loads in the sweeps nothing.
+#ifndef PHK_CK_NT
+#define PHK_CK_NT 1  // A/B: 0 = plain stores; 2 = non-temporal loads in the sweeps as well
+#endif
+template <typename real>
+__device__ __forceinline__ void ck_store(real* p, real v) {
+#if PHK_CK_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename real>
+__device__ __forceinline__ real ck_load(const real* p) {
+#if PHK_CK_NT >= 2
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 struct SeqMap {
     int64_t bb, ss, seq, oseq;
     bool active;     // this group holds a sequence of its own
@@ -1365,7 +1389,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
 #if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
                     for (int i = 0; i < SPL; ++i)
-                        *(real*)(ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))) = L::get(a, i);
+                        ck_store((real*)(ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))), L::get(a, i));
 #endif
                     ck_u += ck_step_b;
                 }
@@ -1438,7 +1462,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                 if constexpr (CKPT) {
 #if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
-                    for (int i = 0; i < SPL; ++i) ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)] = L::get(a, i);
+                    for (int i = 0; i < SPL; ++i) ck_store(&ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)], L::get(a, i));
 #endif
                     ck_u += ck_step;
                 }
@@ -1545,7 +1569,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                   if constexpr (CKPT) {
 #if !PHK_EXP_NO_CKPT_STORE
 #pragma unroll
-                      for (int i = 0; i < SPL; ++i) ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)] = L::get(a, i);
+                      for (int i = 0; i < SPL; ++i) ck_store(&ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)], L::get(a, i));
 #endif
                       ck_u += ck_step;
                   }
@@ -1581,7 +1605,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
         if constexpr (CKPT) {
             if (active) {
 #pragma unroll
-                for (int i = 0; i < SPL; ++i) ckp[L::ck_elem(i, nseq)] = L::get(a, i);
+                for (int i = 0; i < SPL; ++i) ck_store(&ckp[L::ck_elem(i, nseq)], L::get(a, i));
             }
             ckp += ck_step;
         }
@@ -1848,7 +1872,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         ckq += (int64_t)(blk_hi - 1) * ck_step;
         ebq += (int64_t)(blk_hi - 1) * nseq;
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) anext[i] = ckq[L::ck_elem(i, nseq)];
+        for (int i = 0; i < SPL; ++i) anext[i] = ck_load(&ckq[L::ck_elem(i, nseq)]);
         e_next = *ebq;
         ckq -= ck_step;
         ebq -= nseq;
@@ -1886,7 +1910,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         if (blk > blk_lo) {  // prefetch the previous block's checkpoint and exponent under this block's arithmetic
                              // (two blocks ahead: +2 ms at cfg2, profiles/r05_ab_experiments.txt item 13)
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) anext[i] = ckq[L::ck_elem(i, nseq)];
+            for (int i = 0; i < SPL; ++i) anext[i] = ck_load(&ckq[L::ck_elem(i, nseq)]);
             e_next = *ebq;
             ckq -= ck_step;
             ebq -= nseq;
