@@ -53,6 +53,9 @@
 #ifndef PHK_BSCAN_PRIO
 #define PHK_BSCAN_PRIO 0  // s_setprio of the beta scan's waves (they share SIMDs with the forward kernel's)
 #endif
+#ifndef PHK_FWD_PRIO
+#define PHK_FWD_PRIO 1  // s_setprio of the forward kernel's waves where they are the step's critical path (checkpointing, more than one state per lane): the beta scan's waves of the hybrid plan share their SIMDs and finish 3 ms earlier; cfg2 forward 9.39 -> 9.10 ms, 3 = 1 (r05_ab_experiments.txt item 17)
+#endif
 #ifndef PHK_FWD_BIG_PIECES
 #define PHK_FWD_BIG_PIECES 0  // forward kernel with checkpoints: request observation words 256 sites at a time
 #endif
@@ -1122,6 +1125,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     static_assert(T <= 16 && 16 % T == 0, "a block's codes must sit in one dword");
     static_assert(T % NRM == 0, "the rescale schedule must restart with every block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#if PHK_FWD_PRIO
+    if constexpr (CKPT && !has_dense<real, K, R>()) __builtin_amdgcn_s_setprio(PHK_FWD_PRIO);
+#endif
     const int64_t nseq = A.B * A.S;
     const int rank = threadIdx.x & (R - 1);
     // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
