@@ -68,6 +68,20 @@ static int seg_sites_from_env() {
     return 512;
 }
 static const int SEG_SITES = seg_sites_from_env();
+// threads per workgroup of the forward kernel (developer builds: PHK_FWD_NT = 64 | 128 | 256; smaller workgroups lose 55 %:
+// their waves are packed onto one SIMD, profiles/r05_ab_experiments.txt item 18)
+static int fwd_nt_from_env() {
+#ifdef PHK_DEV_OVERRIDES
+    const char* e = std::getenv("PHK_FWD_NT");
+    const int v = e ? std::atoi(e) : 0;
+    if (v == 64 || v == 128 || v == 256) {
+        std::fprintf(stderr, "phk: developer override PHK_FWD_NT=%d is active\n", v);
+        return v;
+    }
+#endif
+    return 256;
+}
+static const int FWD_NT = fwd_nt_from_env();
 inline int seg_blocks(int T) { return SEG_SITES / T; }
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 
@@ -419,7 +433,7 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         HIP_TRY(hipEventRecord(h->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         // (forward kernel first: its 784 lone waves are to be on their SIMDs before the scan's 4,376 fill the slots)
-        e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
+        e = l.fwd(Rf, plan.T, h->nrm, true, a, FWD_NT, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, Rf, plan.T, hipGetErrorString(e));
         e = l.bscan(plan.R2, h->nrm, a2, (int64_t)SEG_SITES, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
         if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (hybrid, K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
@@ -437,7 +451,7 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     }
     if (!plan.segmented) {
         const int Rf = plan.R1 ? plan.R1 : plan.R;
-        e = l.fwd(Rf, plan.T, h->nrm, true, a, nt, st);
+        e = l.fwd(Rf, plan.T, h->nrm, true, a, FWD_NT, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, Rf, plan.T, hipGetErrorString(e));
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         e = l.bwd(plan.R, plan.T, h->nrm, a, 0, nt, st);
