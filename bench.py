@@ -585,6 +585,10 @@ def main():
         if world == 1:
             # the reference's default problem (mcmc.py:119-121, 193): 500 particles x minibatch of 5 x 100,000 windows
             extras["secondary"] = extra_workload("prod", rank, world, dev, local_rank, use_dist, steps=50, warmup=5, het_rate=0.05)
+            # BASELINE.json's other single-GPU configs (K = 64; K = 32 with 500 particles), a few steps each: the
+            # driver runs only this command line, and they would otherwise exist as builder-run files alone
+            extras["other_configs"] = {c: extra_workload(c, rank, world, dev, local_rank, use_dist, steps=3, warmup=1)
+                                       for c in ("cfg4", "cfg5")}
         else:
             # north_star's multi-GPU config: the fixed 5,000-row problem sharded over the ranks
             extras["strong_cfg3"] = extra_workload("cfg3", rank, world, dev, local_rank, use_dist, steps=5, warmup=1,
