@@ -587,8 +587,8 @@ def main():
             extras["secondary"] = extra_workload("prod", rank, world, dev, local_rank, use_dist, steps=50, warmup=5, het_rate=0.05)
             # BASELINE.json's other single-GPU configs (K = 64; K = 32 with 500 particles), a few steps each: the
             # driver runs only this command line, and they would otherwise exist as builder-run files alone
-            extras["other_configs"] = {c: extra_workload(c, rank, world, dev, local_rank, use_dist, steps=3, warmup=1)
-                                       for c in ("cfg4", "cfg5")}
+            extras["other_configs"] = {c: extra_workload(c, rank, world, dev, local_rank, use_dist, steps=n, warmup=w)
+                                       for c, n, w in (("cfg1", 50, 5), ("cfg4", 3, 1), ("cfg5", 3, 1))}
         else:
             # north_star's multi-GPU config: the fixed 5,000-row problem sharded over the ranks
             extras["strong_cfg3"] = extra_workload("cfg3", rank, world, dev, local_rank, use_dist, steps=5, warmup=1,

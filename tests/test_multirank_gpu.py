@@ -131,7 +131,7 @@ def test_bench_plain_form_self_launches_two_ranks():
 
 def test_bench_default_command_on_one_gpu_carries_the_other_shapes():
     """``python bench.py`` at its default sizes: after the cfg2 loop the same process times the reference's production
-    shape (``secondary``) and BASELINE.json's K = 64 and K = 32 configs (``other_configs``), each with the full inner
+    shape (``secondary``) and BASELINE.json's cfg1, K = 64 and K = 32 configs (``other_configs``), each with the full inner
     step and its own checks; ``value`` stays the cfg2 figure."""
     line = _plain_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-reference-kernel"], timeout=1500)
     assert line["n_gpus"] == 1 and line["config"]["name"] == "cfg2" and "strong_cfg3" not in line
@@ -139,11 +139,11 @@ def test_bench_default_command_on_one_gpu_carries_the_other_shapes():
     sec = line["secondary"]
     assert sec["checks_passed"] is True and sec["value"] == pytest.approx(500 * 5 * 100000 / (sec["ms_per_step"] * 1e-3), rel=1e-6)
     other = line["other_configs"]
-    assert set(other) == {"cfg4", "cfg5"}
-    for name, particles in (("cfg4", 100), ("cfg5", 500)):
+    assert set(other) == {"cfg1", "cfg4", "cfg5"}
+    for name, work in (("cfg1", 1 * 1 * 100000), ("cfg4", 100 * 500 * 60000), ("cfg5", 500 * 500 * 60000)):
         ex = other[name]
         assert ex["checks_passed"] is True and ex["scaling"] == "weak" and ex["n_gpus"] == 1
-        assert ex["value"] == pytest.approx(particles * 500 * 60000 / (ex["ms_per_step"] * 1e-3), rel=1e-6)
+        assert ex["value"] == pytest.approx(work / (ex["ms_per_step"] * 1e-3), rel=1e-6)
 
 
 def test_bench_default_command_at_two_ranks_carries_the_strong_scaling_extra():
