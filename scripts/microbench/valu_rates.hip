@@ -16,6 +16,8 @@ __global__ void bench(float* out, long long* cyc, int iters) {
     v2 a = {out[threadIdx.x], out[threadIdx.x + 1]}, b = {1.0001f, 0.9999f}, c = {1e-3f, 1e-3f};
     v2 x0 = a, x1 = a + c, x2 = a - c, x3 = a * b;
     float s0 = a.x, s1 = a.y, s2 = c.x, s3 = c.y;
+    float x = a.x + 1.0f, m[16];
+    for (int k = 0; k < 16; ++k) m[k] = 0.0625f + 1e-4f * (float)k * a.y;
     long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
         if constexpr (KIND == 0) {  // dependent v_fma_f32
@@ -46,11 +48,80 @@ __global__ void bench(float* out, long long* cyc, int iters) {
         } else if constexpr (KIND == 9) {  // 4 independent v_pk_mul_f32 / v_pk_add_f32 mixed
             asm volatile(REP16("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n")
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(b), "v"(c));
+        } else if constexpr (KIND == 10) {  // dense 16 x 16 step of the one-state-per-lane kernels, 4 accumulator chain(s); 4 steps per iteration, each on the result of the one before
+            for (int rep = 0; rep < 4; ++rep) {
+                float c0, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                asm volatile("s_nop 1\n"
+                "v_mul_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_mul_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_mul_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_mul_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+                    : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+                x = (c0 + c1) + (c2 + c3);
+            }
+        } else if constexpr (KIND == 11) {  // dense 16 x 16 step of the one-state-per-lane kernels, 1 accumulator chain(s); 4 steps per iteration, each on the result of the one before
+            for (int rep = 0; rep < 4; ++rep) {
+                float c0, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                asm volatile("s_nop 1\n"
+                "v_mul_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+                    : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+                x = c0;
+            }
+        } else if constexpr (KIND == 12) {  // dense 16 x 16 step of the one-state-per-lane kernels, 2 accumulator chain(s); 4 steps per iteration, each on the result of the one before
+            for (int rep = 0; rep < 4; ++rep) {
+                float c0, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                asm volatile("s_nop 1\n"
+                "v_mul_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_mul_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %0, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f32_dpp %1, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+                    : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+                x = c0 + c1;
+            }
         }
     }
     long long t1 = __builtin_readcyclecounter();
     v2 r = x0 + x1 + x2 + x3;
-    out[threadIdx.x + blockIdx.x * blockDim.x] = r.x + r.y + s0 + s1 + s2 + s3;
+    out[threadIdx.x + blockIdx.x * blockDim.x] = r.x + r.y + s0 + s1 + s2 + s3 + x;
     if (threadIdx.x % 64 == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
@@ -87,6 +158,9 @@ int main() {
         run<9>("4 chains of v_pk_mul_f32 / v_pk_add_f32", w, out, cyc);
         run<7>("v_pk_fma_f32 chain + independent v_fma_f32 (per instr)", w, out, cyc);
         run<6>("s_nop 0", w, out, cyc);
+        run<10>("dense16 step, 4 accumulators (per 16 steps of 64: x16)", w, out, cyc);
+        run<11>("dense16 step, 1 accumulator", w, out, cyc);
+        run<12>("dense16 step, 2 accumulators", w, out, cyc);
     }
     return 0;
 }
