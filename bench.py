@@ -482,6 +482,8 @@ def main():
 
     use_fused = not a.autograd_step and fused_step.fusable(template, kern)
 
+    timing_only = os.environ.get("PHK_BENCH_TIMING_ONLY") == "1"
+
     def one_step(state):
         nonlocal inds
         if draws is not None:
@@ -492,6 +494,9 @@ def main():
             # a fixed sequence of HIP launches (phlash_amd/step.py), then the SVGD update
             _, g = fused_step.log_density_and_grad(template, state.particles, (1.0, c1, 1.0), kern, inds, afs)
             flags.add_(kern._flags)
+            if timing_only:  # (timing-only library builds return garbage: the update is computed and dropped)
+                svgd.step(state, g, lr=0.1)
+                return state
             return svgd.step(state, g, lr=0.1)
         # the same step through autograd (the definition the fused path is tested against; --autograd-step)
         xs = state.particles.detach().requires_grad_(True)

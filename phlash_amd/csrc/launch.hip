@@ -74,13 +74,24 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
     const int64_t nseq = (a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin;
     // variants that park part of a block in LDS (psmc_kernels.hip, sweep_parked) run as workgroups of two waves: four
     // of them share a CU's 160 KB and a workgroup stays under the 64 KB a launch gets without asking
+    // A slice above the 64 KB a launch gets without asking (round 6: the folded float32 sweeps park three w vectors, 76
+    // floats per thread = 77,824 B per 256-thread workgroup) is asked for per kernel, once: two such workgroups still fit
+    // a CU's 160 KB, i.e. two waves per SIMD as the kernels are compiled for.  Round 5 fell back to 128-thread workgroups
+    // there, whose two waves land on ONE SIMD (profiles/r05_ab_experiments.txt item 2).
     constexpr int stride = sweep_lds_stride<real_t, KK, R, T, NRM>();
-    if ((size_t)stride * nt * sizeof(real_t) > 65536) nt = 128;
+    constexpr size_t lds256 = (size_t)stride * 256 * sizeof(real_t);
+    constexpr bool big_lds = lds256 > 65536 && 2 * lds256 <= 163840;
+    if ((size_t)stride * nt * sizeof(real_t) > 65536 && !big_lds) nt = 128;
     const size_t lds = (size_t)stride * nt * sizeof(real_t);
     const int spb = nt / R;
     const dim3 block(nt);
     if (units <= 0) {  // one serial sweep per sequence
         if constexpr (f64_sweep_ok<R, false>()) {
+            if constexpr (big_lds) {
+                static const hipError_t attr = hipFuncSetAttribute((const void*)bwd_kernel<real_t, KK, R, T, NRM, false>,
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                if (attr != hipSuccess) return attr;
+            }
             const dim3 grid((unsigned)((nseq + spb - 1) / spb));
             hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, false>), grid, block, lds, st, a);
         } else {
@@ -88,6 +99,11 @@ static hipError_t bwd_rtn(const KArgs& a, int units, int nt, hipStream_t st) {
         }
     } else {  // `units` independent segments per sequence
         if constexpr (f64_sweep_ok<R, true>()) {
+            if constexpr (big_lds) {
+                static const hipError_t attr = hipFuncSetAttribute((const void*)bwd_kernel<real_t, KK, R, T, NRM, true>,
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+                if (attr != hipSuccess) return attr;
+            }
             const dim3 grid((unsigned)((nseq + spb - 1) / spb), (unsigned)units);
             hipLaunchKernelGGL((bwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds, st, a);
         } else {

@@ -73,6 +73,20 @@
                     // workgroups, whose two waves land on one SIMD (cfg2 backward phase 25.1 instead of 20.1 ms,
                     // profiles/r05_ab_experiments.txt item 2)
 #endif
+#ifndef PHK_HET_REGS
+#define PHK_HET_REGS 1  // folded sweeps (round 6): the het ratio row emis1 / emis0 and the het posterior mass live in REGISTERS in the hot
+                        // body (two more parked w vectors pay for them), het lanes are handled under the exec mask, the block's
+                        // non-hom mask comes from two readlanes where the wave holds at most two observation rows; only missing
+                        // sites still go through the LDS rows.  0 = round 5's body (every non-hom site through LDS)
+#endif
+#ifndef PHK_FWD_HET_REGS
+#define PHK_FWD_HET_REGS 0  // A/B: 1 = forward kernels with several states per lane, folded waves: the het / missing ratio rows in registers
+                           // instead of the LDS table.  Measured and not adopted (profiles/r06_ab_experiments.txt item 3): the one-lane
+                           // K = 16 kernel goes from 236 registers to 255 + 14 AGPR copies, 0.37 ms slower at 1 % hets, level at 10 %
+#endif
+#ifndef PHK_EXP_HET_MODE
+#define PHK_EXP_HET_MODE 0  // timing-only diagnostic builds of the PHK_HET_REGS body: 1 = no site is het or missing, 2 = branches taken, bodies empty
+#endif
 #ifndef PHK_EXP_NO_STEEP
 #define PHK_EXP_NO_STEEP 0
 #endif
@@ -1168,6 +1182,15 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // one-lane forward kernel without them ran cfg2's forward phase in 8.1 instead of 10.8 ms); any other block takes
     // the straight-line path with per-lane codes as ever, its rows now the ratios emis1 / emis0, 1 / emis0 and 1.
     constexpr bool FOLD = !DENSE && sizeof(real) == 4 && PHK_FWD_FOLD != 0;
+    constexpr bool FREG = FOLD && PHK_FWD_HET_REGS != 0;
+    V rhet[NP], rmis[NP];  // FREG: a folded lane's ratio rows emis1 / emis0 and 1 / emis0 (see fold_block)
+    if constexpr (FREG) {
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            rhet[h] = *(const V*)(lane.etab + L::EROW + 2 * h);
+            rmis[h] = *(const V*)(lane.etab + 2 * L::EROW + 2 * h);
+        }
+    }
     bool uni2 = false, rowB = false;
     if constexpr (FOLD) {
         const int sA = __builtin_amdgcn_readfirstlane((int)ss), sB = __builtin_amdgcn_readlane((int)ss, 63);
@@ -1430,7 +1453,24 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             V none[NP];
             real sc;
             lane.template fwd_site<false>(a, none, sc, false);
-            if (__builtin_expect((nhm >> (2 * i)) & 1u, 0)) {
+            if constexpr (FREG) {
+                // round 6: the two ratio rows in registers, het / missing lanes multiply under the exec mask behind one
+                // wave-uniform bit each (round 5: the lane's row from the LDS table, a round trip a lone wave cannot hide)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) asm volatile("" : : "v"(rhet[h]), "v"(rmis[h]));  // (a use on the hot path: see bwd_kernel)
+                if (__builtin_expect((cu >> (2 * i)) & 1u, 0)) {
+                    if (((mine >> (2 * i)) & 3u) == 1u) {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) a[h] = a[h] * rhet[h];
+                    }
+                }
+                if (__builtin_expect((cu >> (2 * i + 1)) & 1u, 0)) {
+                    if (((mine >> (2 * i)) & 3u) == 2u) {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) a[h] = a[h] * rmis[h];
+                    }
+                }
+            } else if (__builtin_expect((nhm >> (2 * i)) & 1u, 0)) {
                 V e[NP];
                 lane.emis((mine >> (2 * i)) & 3, e);
 #pragma unroll
@@ -1718,13 +1758,22 @@ constexpr int bwd_waves_per_simd() {
 // code like the table itself.
 template <typename real, int K, int R, int T, int NRM>
 constexpr bool sweep_folds() { return PHK_SWEEP_FOLD != 0 && sizeof(real) == 4 && PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * (K / R) * (int)sizeof(real) <= 256; }
+#ifndef PHK_PARK_HREG
+#define PHK_PARK_HREG 2  // ... of the folded bodies with PHK_HET_REGS: 68 floats of LDS per thread = 69,632 B per 256-thread workgroup, two
+                         // workgroups per CU (the launcher raises the kernel's dynamic-LDS limit: launch.hip, bwd_rtn).  Every parked
+                         // vector costs ~0.25 ms of cfg2's backward phase (1 / 2 / 3 / 5 parked: spills in the block loop / 19.2 / 19.4 /
+                         // 20.9 ms, profiles/r06_ab_experiments.txt item 2); 2 is the fewest that keeps the block loop out of scratch
+#endif
+#ifndef PHK_PARK_HREG2
+#define PHK_PARK_HREG2 5  // ... with PHK_HET_REGS == 2 (the missing row and its mass in registers as well, no mass rows in LDS): 28 + 40 floats
+#endif
 #ifndef PHK_PARK_UNFOLDED
 #define PHK_PARK_UNFOLDED 3  // ... of the bodies that keep their emission rows (float64): round 3's figure
 #endif
 template <typename real, int K, int R, int T, int NRM>
 constexpr int sweep_parked() {
     if (!(PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && (K / R) * (int)sizeof(real) == 32)) return 0;
-    return sweep_folds<real, K, R, T, NRM>() ? PHK_PARK : PHK_PARK_UNFOLDED;
+    return sweep_folds<real, K, R, T, NRM>() ? (PHK_HET_REGS == 2 ? PHK_PARK_HREG2 : PHK_HET_REGS != 0 ? PHK_PARK_HREG : PHK_PARK) : PHK_PARK_UNFOLDED;
 }
 // reals per thread of the backward kernel's LDS slice: emission table + mass rows + parked vectors, the stride in 16-byte
 // units odd (the 16 lanes of a ds_read_b128 group then fall on 16 different bank quads, see Lane::ETAB_STRIDE)
@@ -1732,7 +1781,7 @@ template <typename real, int K, int R, int T, int NRM>
 constexpr int sweep_lds_stride() {
     using L = Lane<real, K, R>;
     constexpr int park = sweep_parked<real, K, R, T, NRM>() * 2 * L::NP;
-    constexpr int gtab = sweep_folds<real, K, R, T, NRM>() ? 3 * L::EROW : 0;
+    constexpr int gtab = (sweep_folds<real, K, R, T, NRM>() && PHK_HET_REGS != 2) ? 3 * L::EROW : 0;
     if (park + gtab == 0) return L::ETAB_STRIDE;
     constexpr int per16 = 16 / (int)sizeof(real);
     int n = L::ETAB_STRIDE + gtab + park;
@@ -1777,9 +1826,9 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     constexpr bool SFOLD = sweep_folds<real, K, R, T, NRM>();
     real* etab = (real*)smem_raw + (size_t)tid * sweep_lds_stride<real, K, R, T, NRM>();
     real* const gtab = etab + L::ETAB_STRIDE;                     // SFOLD: posterior-mass rows [3][EROW], by code
-    real* const park = gtab + (SFOLD ? 3 * L::EROW : 0);          // parked w vectors
+    real* const park = gtab + ((SFOLD && PHK_HET_REGS != 2) ? 3 * L::EROW : 0);  // parked w vectors
     lane.load(prm, rank, etab, pi);
-    if constexpr (SFOLD) {
+    if constexpr (SFOLD && PHK_HET_REGS != 2) {
 #pragma unroll
         for (int j = 0; j < 3 * L::EROW; ++j) gtab[j] = real(0);
     }
@@ -1801,6 +1850,21 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     const bool folded = lane.try_fold();  // (per sequence)
     const int g0code = (SFOLD && folded) ? 2 : 0;
     const bool wave_folded = SFOLD && __all(folded) != 0;
+    // HREG (round 6): what a het site needs in the hot body -- its ratio row and the row its posterior mass is booked in --
+    // lives in registers; see the hot body.  A wave that holds a sequence which cannot fold takes the general body.
+    constexpr bool HREG = SFOLD && PHK_HET_REGS != 0;
+    constexpr bool HREG2 = SFOLD && PHK_HET_REGS == 2;  // ... and so does what a missing site needs: no mass rows in LDS at all
+    V rhet[NP], rmis[NP];
+    bool two_rows = false;  // every lane of the wave reads the observation row of lane 0 or that of lane 63
+    if constexpr (HREG) {
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            rhet[h] = *(const V*)(etab + L::EROW + 2 * h);
+            rmis[h] = *(const V*)(etab + 2 * L::EROW + 2 * h);
+        }
+        const int sA = __builtin_amdgcn_readfirstlane((int)ss), sB = __builtin_amdgcn_readlane((int)ss, 63);
+        two_rows = __all((int)ss == sA || (int)ss == sB) != 0;
+    }
     if constexpr (SEG) {
         if (active && rank == 0 && blockIdx.y == 0) A.aux[seq].folded = folded ? (SFOLD ? 1 : 2) : 0;
     }
@@ -1926,11 +1990,12 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     // fold the partial sums into float64 (units >= 1 of the segment sweep: store them, exactly once, at their left edge)
     auto flush = [&]() {
         since_flush = 0;
-        if constexpr (SFOLD) {  // the mass rows of the folded form live in LDS (see the hot body): row g0code and the het row
+        if constexpr (SFOLD && !HREG2) {  // the mass rows of the folded form live in LDS (see the hot body): row g0code and the het row
 #pragma unroll
             for (int h = 0; h < NP; ++h) {
                 g0[h] = *(const V*)(gtab + g0code * L::EROW + 2 * h);
-                g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
+                if constexpr (HREG) g1[h] = g1[h] + *(const V*)(gtab + 1 * L::EROW + 2 * h);  // (registers: hot body; LDS row: general body)
+                else g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
             }
 #pragma unroll
             for (int j = 0; j < 3 * L::EROW; ++j) gtab[j] = real(0);
@@ -1974,7 +2039,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #endif
     int blk = blk_hi - 1;
     while (blk >= blk_lo) {
-        if (!HOT || wave_steep || blk == blkW || blk == blk_part) {
+        if (!HOT || wave_steep || (HREG && !wave_folded) || blk == blkW || blk == blk_part) {
             const int64_t t0 = (int64_t)blk * T;
             V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
             real sc[T / NRM];
@@ -2029,7 +2094,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                     const bool SC = rescale_after<NRM>(i);
                     V e[NP];
                     lane.emis((codes >> (2 * i)) & 3, e);
-                    if constexpr (SFOLD)
+                    if constexpr (SFOLD && !HREG2)
                         lane.bwd_site(al[i], al[i + 1], beta, e, (codes >> (2 * i)) & 3, SC ? sc[i / NRM] : real(1), SC,
                                       gb, gd, gu, gv, m0, m1, g0code);
                     else
@@ -2037,7 +2102,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                                       gb, gd, gu, gv, g0, g1, g0code);
                 }
             }
-            if constexpr (SFOLD) {
+            if constexpr (SFOLD && !HREG2) {
 #pragma unroll
                 for (int h = 0; h < NP; ++h) {
                     V* r0 = (V*)(gtab + g0code * L::EROW + 2 * h);
@@ -2091,7 +2156,181 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                     // pass: the longest lifetimes), the others in registers
                     constexpr int NREG = T - PARKN;
                     V w[NREG > 0 ? NREG : 1][NP];
-                    if constexpr (SFOLD) {
+                    if constexpr (HREG) {
+                        // Folded form, round 6.  As below (ONE body, a wave-uniform branch per site and pass on one bit of the
+                        // block's non-hom mask), but what a HET site needs is in registers: its ratio row `rhet` and the
+                        // row `g1` its posterior mass goes to.  Round 5 fetched the ratio row from the LDS table and booked
+                        // the mass by a read-modify-write of an LDS row: three LDS round trips in the dependency chain of
+                        // every het site, which cost such a site as much again as the 90 vector instructions of the site
+                        // itself (cfg2: 20.1 ms at 1 % hets, 23.8 at 10 %).  Het lanes now multiply and accumulate under
+                        // the exec mask (a lane whose row is hom at this site does nothing: two-row waves), and only
+                        // MISSING sites -- runs of masked windows in real data, 1 % of the bench rows -- still go through
+                        // the LDS rows, behind a second wave-uniform bit.  The sixteen registers are paid for by parking
+                        // three of the block's w vectors in LDS instead of one (sweep_parked).
+                        // The block's masks: with sequences stored chunk-major a wave holds one or two observation rows
+                        // whenever B >= the wave's sequence count, so the OR over the wave of the block's 16 code bits is
+                        // the OR of lane 0's and lane 63's -- two readlanes instead of round 5's eight ballots.
+                        uint32_t u16;
+                        {
+                            const uint32_t c16 = codes & 0xffffu;
+                            if (__builtin_expect(two_rows, 1)) {
+                                u16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c16) | (uint32_t)__builtin_amdgcn_readlane((int)c16, 63);
+                            } else {
+                                u16 = 0u;
+                                if (__any(c16 != 0u)) {
+#pragma unroll
+                                    for (int i = 0; i < 2 * T; ++i) u16 |= __any((c16 >> i) & 1u) ? (1u << i) : 0u;
+                                }
+                            }
+                        }
+#if PHK_EXP_HET_MODE == 1  // timing-only diagnostic builds (results are wrong): no site is treated as het or missing
+                        u16 = 0u;
+#endif
+                        const uint32_t nm = (u16 >> 1) & 0x5555u;  // bit 2i: site i is missing in some lane
+                        const uint32_t nh = (u16 | (u16 >> 1)) & 0x5555u;  // bit 2i: site i is not hom in some lane
+#pragma unroll
+                        for (int i = T - 1; i >= 0; --i) {
+                            V wi[NP];
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wi[h] = beta[h];
+                            // (a use on the hot path: read only in branches the compiler knows to be cold, the ratio row is
+                            // its first choice for scratch -- reloaded inside every het branch, worse than the LDS table)
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) {
+                                asm volatile("" : : "v"(rhet[h]));
+                                if constexpr (HREG2) asm volatile("" : : "v"(rmis[h]));
+                            }
+                            if (__builtin_expect((nh >> (2 * i)) & 1u, 0)) {
+                                const uint32_t c = (codes >> (2 * i)) & 3u;
+#if PHK_EXP_HET_MODE == 2  // timing-only: the branch is taken, its body is one instruction
+                                asm volatile("s_nop 0");
+#else
+                                if (c == 1u) {
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) wi[h] = beta[h] * rhet[h];
+                                }
+#endif
+                                if (PHK_EXP_HET_MODE != 2 && __builtin_expect((nm >> (2 * i)) & 1u, 0)) {
+                                    if constexpr (HREG2) {
+                                        if (c == 2u) {
+#pragma unroll
+                                            for (int h = 0; h < NP; ++h) wi[h] = beta[h] * rmis[h];
+                                        }
+                                    } else {
+                                        V e[NP];
+                                        lane.emis(c == 2u ? 2 : 0, e);  // (row 0 of a folded lane: ones)
+#pragma unroll
+                                        for (int h = 0; h < NP; ++h) wi[h] = wi[h] * e[h];
+                                    }
+                                }
+                            }
+                            if (i >= NREG) {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) *(V*)(park + ((i - NREG) * NP + h) * 2) = wi[h];
+                            } else {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) w[i][h] = wi[h];
+                            }
+                            V svw[NP], pbw[NP], cb;
+                            lane.scans_adj(wi, svw, pbw, cb);
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) beta[h] = lane.beta_prev(h, wi, svw, pbw, cb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        V a[NP];
+#pragma unroll
+                        for (int h = 0; h < NP; ++h) a[h] = al0[h];
+                        V wc[NP];  // w of the current site; a parked one is requested one site ahead
+                        if (NREG > 0) {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wc[h] = w[0][h];
+                        } else {
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) wc[h] = *(const V*)(park + h * 2);
+                        }
+                        // (the forward pass tests copies of the masks the compiler cannot connect with the beta pass's: it
+                        // otherwise keeps every site's bit as a 64-bit lane mask from one pass to the other, seven scalar
+                        // instructions per site for the two tests instead of four)
+                        uint32_t nh_f = nh, nm_f = nm;
+                        asm volatile("" : "+s"(nh_f), "+s"(nm_f));
+#pragma unroll
+                        for (int i = 0; i < T; ++i) {
+                            V wn[NP];
+                            if (i + 1 < T) {
+                                if (i + 1 >= NREG) {
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) wn[h] = *(const V*)(park + ((i + 1 - NREG) * NP + h) * 2);
+                                } else {
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) wn[h] = w[i + 1 < NREG ? i + 1 : 0][h];
+                                }
+                            }
+                            V pre[NP], suf[NP], svw[NP], t[NP];
+                            lane.scans(a, pre, suf);
+                            lane.suffix_vw(wc, svw);
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) {
+                                gd[h] = fma2<real>(wc[h], a[h], gd[h]);
+                                gb[h] = fma2<real>(wc[h], suf[h], gb[h]);
+                                gv[h] = fma2<real>(wc[h], pre[h], gv[h]);
+                                gu[h] = fma2<real>(a[h], svw[h], gu[h]);
+                                V tt = lane.d[h] * a[h];
+                                tt = fma2<real>(lane.v[h], pre[h], tt);
+                                t[h] = fma2<real>(lane.b[h], suf[h], tt);
+                            }
+                            // (the four rows are pinned here: see the round-5 body below; the mass rows and the ratio rows for the
+                            // reason given in the beta pass)
+#pragma unroll
+                            for (int h = 0; h < NP; ++h) {
+                                asm volatile("" : "+v"(gd[h]), "+v"(gb[h]), "+v"(gv[h]), "+v"(gu[h]), "+v"(g1[h]) : "v"(rhet[h]));
+                                if constexpr (HREG2) asm volatile("" : "+v"(g0[h]) : "v"(rmis[h]));
+                            }
+                            if (__builtin_expect((nh_f >> (2 * i)) & 1u, 0)) {
+                                const uint32_t c = (codes >> (2 * i)) & 3u;
+#if PHK_EXP_HET_MODE == 2
+                                asm volatile("s_nop 0");
+#else
+                                if (c == 1u) {  // het lanes: the site's posterior mass p .* w, then the ratio row
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) {
+                                        g1[h] = fma2<real>(t[h], wc[h], g1[h]);
+                                        t[h] = t[h] * rhet[h];
+                                    }
+                                }
+#endif
+                                if (PHK_EXP_HET_MODE != 2 && HREG2 && __builtin_expect((nm_f >> (2 * i)) & 1u, 0)) {
+                                    if (c == 2u) {  // missing lanes: the same with their own rows
+#pragma unroll
+                                        for (int h = 0; h < NP; ++h) {
+                                            g0[h] = fma2<real>(t[h], wc[h], g0[h]);
+                                            t[h] = t[h] * rmis[h];
+                                        }
+                                    }
+                                }
+                                if (PHK_EXP_HET_MODE != 2 && !HREG2 && __builtin_expect((nm_f >> (2 * i)) & 1u, 0)) {
+                                    // a missing site: mass into LDS row 2 and the row 1 / emis0 (a lane that is not missing
+                                    // here adds to row 0, which nobody reads, and multiplies by ones)
+                                    const int row = c == 2u ? 2 : 0;
+                                    real* grow = gtab + row * L::EROW;
+                                    const V* erow = (const V*)(etab + row * L::EROW);
+#pragma unroll
+                                    for (int h = 0; h < NP; ++h) {
+                                        V* gr = (V*)(grow + 2 * h);
+                                        *gr = fma2<real>(t[h], wc[h], *gr);
+                                        t[h] = t[h] * erow[h];
+                                    }
+                                }
+                            }
+                            if (i + 1 < T) {
+#pragma unroll
+                                for (int h = 0; h < NP; ++h) {
+                                    a[h] = t[h];
+                                    wc[h] = wn[h];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if constexpr (SFOLD) {
                         // Folded form: ONE body.  A site that is hom in every lane of the wave multiplies by no emission
                         // row and books no posterior mass (its row is 1 and its mass is part of the remainder, see where
                         // the wave folds its emissions); any other site does both behind a wave-uniform branch on one bit
@@ -2350,7 +2589,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
         }
         return;  // grad_finalize_kernel turns gacc / bpi into the gradient
     }
-    if constexpr (SFOLD && !F64ACC) {  // (never flushed: the mass rows are still in LDS)
+    if constexpr (SFOLD && !HREG2 && !F64ACC) {  // (never flushed: the mass rows are still in LDS)
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             g0[h] = *(const V*)(gtab + g0code * L::EROW + 2 * h);
