@@ -564,24 +564,40 @@ def main():
         assert float(flags[1]) == 0, "a chunk index was out of range"
         assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
     ranks_identical = None
+    fault = os.environ.get("PHK_BENCH_TEST_FAULT", "")  # tests only: "diverge" / "ranks" provoke the two loud exits below
     if use_dist and world > 1:  # the replicated state must be identical on every rank
+        if fault == "diverge" and rank == world - 1:
+            state.particles[0, 0] += 1e-3
         lo, hi = state.particles.clone(), state.particles.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        # reported, not asserted: a scaling run that found a difference should still say how fast it ran --
-        # and that it found one (max |difference| over ranks, 0.0 when the replicas agree to the last bit)
+        # (max |difference| over ranks, 0.0 when the replicas agree to the last bit)
         ranks_identical = bool((lo == hi).all())
-        if not ranks_identical and rank == 0:
-            print(f"WARNING: ranks disagree on the particles after the timed loop (max difference "
-                  f"{float((hi - lo).abs().max()):.3e})", file=sys.stderr, flush=True)
+        if not ranks_identical:
+            # A multi-rank value is only a measurement of THIS job if every rank ran the same job: the line is not printed
+            # and every rank exits non-zero (round 5 reported the flag and exited 0).
+            if rank == 0:
+                print(f"bench.py: FAILED: ranks disagree on the particles after the timed loop (max difference "
+                      f"{float((hi - lo).abs().max()):.3e}); no result line is printed", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
 
-    # how many ranks the RCCL communicator really joins: counted by the communicator itself (a SUM all-reduce of ones
-    # on the GPU), not read from WORLD_SIZE
+    # how many ranks the communicator really joins: counted by the communicator itself (a SUM all-reduce of ones on the
+    # GPU), not read from WORLD_SIZE.  A job whose communicator came up with another count than it was launched with must
+    # not print a value (round 5 reported the count and exited 0).
     rccl_ranks = 0
-    if use_dist and a.backend == "nccl":
+    if use_dist:
         ones = torch.ones(1, dtype=torch.float32, device=dev)
         dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+        comm_ranks = int(ones.item()) - (1 if fault == "ranks" else 0)
+        if a.backend == "nccl":
+            rccl_ranks = comm_ranks
+        if comm_ranks != world:
+            if rank == 0:
+                print(f"bench.py: FAILED: the {a.backend} communicator joins {comm_ranks} rank(s) but WORLD_SIZE={world}; "
+                      f"no result line is printed", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(4)
     # extra workloads, same process, after the headline loop (all ranks take part; rank 0 keeps the dicts)
     extras = {}
     sized_as_config = all(getattr(a, k) == CONFIGS[a.config][k] for k in ("K", "particles", "chunks", "chunk_size", "overlap"))
@@ -594,6 +610,13 @@ def main():
             # driver runs only this command line, and they would otherwise exist as builder-run files alone
             extras["other_configs"] = {c: extra_workload(c, rank, world, dev, local_rank, use_dist, steps=n, warmup=w)
                                        for c, n, w in (("cfg1", 50, 5), ("cfg4", 3, 1), ("cfg5", 3, 1))}
+            # the headline shape on rows with the het rates a human genome has per 100-bp window:
+            # the step cost must not depend on the data
+            for tag, hr in (("cfg2_het5", 0.05), ("cfg2_het10", 0.10)):
+                extras["other_configs"][tag] = extra_workload("cfg2", rank, world, dev, local_rank, use_dist, steps=3, warmup=1, het_rate=hr)
+            # BASELINE.json configs[2] on ONE GPU (5,000 chunk rows, AFS term for n = 20): the N = 1 anchor of the
+            # strong-scaling figure the N > 1 runs print as strong_cfg3
+            extras["other_configs"]["cfg3"] = extra_workload("cfg3", rank, world, dev, local_rank, use_dist, steps=3, warmup=1)
         else:
             # north_star's multi-GPU config: the fixed 5,000-row problem sharded over the ranks
             extras["strong_cfg3"] = extra_workload("cfg3", rank, world, dev, local_rank, use_dist, steps=5, warmup=1,

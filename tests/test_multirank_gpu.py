@@ -139,10 +139,13 @@ def test_bench_default_command_on_one_gpu_carries_the_other_shapes():
     sec = line["secondary"]
     assert sec["checks_passed"] is True and sec["value"] == pytest.approx(500 * 5 * 100000 / (sec["ms_per_step"] * 1e-3), rel=1e-6)
     other = line["other_configs"]
-    assert set(other) == {"cfg1", "cfg4", "cfg5"}
-    for name, work in (("cfg1", 1 * 1 * 100000), ("cfg4", 100 * 500 * 60000), ("cfg5", 500 * 500 * 60000)):
+    # (round 6: the headline shape at 5 % / 10 % het rows and cfg3 -- 5,000 rows, AFS n = 20 -- at N = 1 ride along too)
+    assert set(other) == {"cfg1", "cfg4", "cfg5", "cfg2_het5", "cfg2_het10", "cfg3"}
+    assert "Bernoulli(0.1)" in other["cfg2_het10"]["workload"] and "Bernoulli(0.05)" in other["cfg2_het5"]["workload"]
+    for name, work in (("cfg1", 1 * 1 * 100000), ("cfg4", 100 * 500 * 60000), ("cfg5", 500 * 500 * 60000),
+                       ("cfg2_het5", 100 * 500 * 60000), ("cfg2_het10", 100 * 500 * 60000), ("cfg3", 100 * 5000 * 60000)):
         ex = other[name]
-        assert ex["checks_passed"] is True and ex["scaling"] == "weak" and ex["n_gpus"] == 1
+        assert ex["checks_passed"] is True and ex["scaling"] == ("strong" if name == "cfg3" else "weak") and ex["n_gpus"] == 1
         assert ex["value"] == pytest.approx(work / (ex["ms_per_step"] * 1e-3), rel=1e-6)
 
 
@@ -159,6 +162,22 @@ def test_bench_default_command_at_two_ranks_carries_the_strong_scaling_extra():
     assert ex["scaling"] == "strong" and ex["n_gpus"] == 2 and ex["checks_passed"] is True
     assert ex["value"] == pytest.approx(100 * 64 * 60000 / (ex["ms_per_step"] * 1e-3), rel=1e-6)
     assert "speedup_vs_expectation_n1" in ex and line["rccl_ranks"] == 0  # (gloo: no RCCL communicator here)
+
+
+@pytest.mark.parametrize("fault,code,msg", [("ranks", 4, "communicator joins 1 rank(s) but WORLD_SIZE=2"),
+                                            ("diverge", 3, "ranks disagree on the particles")])
+def test_bench_multi_rank_run_that_is_not_one_job_fails_loudly(fault, code, msg):
+    """A multi-rank run whose communicator joins another number of ranks than it was launched with, or whose replicated
+    particles differ between the ranks after the timed loop, prints NO result line and exits non-zero (round 5 reported
+    both as fields of a line that exited 0).  Provoked through the test hook PHK_BENCH_TEST_FAULT: a faked count, a
+    perturbed replica."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PHK_BENCH_TEST_FAULT"] = fault
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--particles", "12", "--chunks", "40", "--chunk-size", "4000", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0 and not any(ln.startswith("{") for ln in p.stdout.splitlines()), (p.returncode, p.stdout[-500:])
+    assert "FAILED" in p.stderr and msg in p.stderr and f"rank exit codes [{code}, {code}]" in p.stderr, p.stderr[-2000:]
 
 
 def test_bench_cfg3_eight_ranks_gloo_tiny():
