@@ -561,7 +561,7 @@ def main():
         }
     if os.environ.get("PHK_BENCH_TIMING_ONLY") != "1":  # (set for timing-only library builds that leave work out: scripts/ab_build.sh)
         assert bool(torch.isfinite(state.particles).all()), "particles went non-finite"
-        assert float(flags[1]) == 0, "a chunk index was out of range"
+        assert float(flags[1]) == 0, "a chunk index was out of range, or a kernel loop ran out of its iteration budget (flag slot 1)"
         assert float(flags[0]) == 0, "the rescale interval was too long for these particles"
     ranks_identical = None
     fault = os.environ.get("PHK_BENCH_TEST_FAULT", "")  # tests only: "diverge" / "ranks" provoke the two loud exits below

@@ -36,6 +36,9 @@ extern "C" {
 #define PHK_ENOMEM 2   /* device allocation failed (the reference raises MemoryError: gpu.py:117-124) */
 #define PHK_EHIP 3     /* HIP runtime error (the reference raises CudaError/RuntimeError) */
 #define PHK_EUNSUPPORTED 4 /* K / variant not compiled in */
+#define PHK_EOVERRUN 5 /* a kernel loop ran out of the iteration budget the host derived from the row length: the kernel
+                          returned early, the evaluation is invalid; phk_last_error() names kernel, sequence and block.
+                          (No counterpart in the reference, whose kernels loop over ``L`` alone: gpu.py:541, 617.) */
 
 typedef struct phk_handle phk_handle;
 
@@ -76,6 +79,38 @@ int phk_destroy(phk_handle* h);
 int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s,
                const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad,
                int grad_dlog, void* stream);
+
+/* float64 parameter blocks -> what a float32 kernel object runs on, one launch.  The reference rounds its float64
+ * PSMCParams to the kernel's float type field by field on the host (src/phlash/gpu.py:200-214, ``astype(float_type)``);
+ * the float32 kernels here additionally run on the model written with hom emission 1 ("folded"):
+ *   params       device double [nblocks, 7, K]  rows b,d,u,v,emis0,emis1,pi (gpu.py:189)
+ *   params_f32   device float  [nblocks, 7, K]  the same block rounded to float32
+ *   prefold_f32  device float  [nblocks, 5, K]  rows fl(emis0 b), fl(emis0 d), fl(emis0 v), fl(emis1 / emis0), fl(1 / emis0),
+ *                each formed in float64 and rounded ONCE.  Handed to phk_loglik_prefolded beside params_f32 the kernels
+ *                take these factors as they are; without them (phk_loglik) they fold the float32 rows themselves, which
+ *                rounds every folded factor three times -- an error that is the same at every site of a row and adds up
+ *                along it.
+ *   crel         device double [nblocks, 7, K] or NULL: coefficients of the first-order correction phk_ll_first_order applies */
+int phk_prefold(int device, int K, const double* params, int64_t nblocks, float* params_f32, float* prefold_f32, double* crel,
+                void* stream);
+
+/* First-order correction of a float32 gradient call's log-likelihoods for the rounding of the model to float32:
+ *     ll[b, s] += sum_j theta[b, s, j] * (d ll / d theta)[b, s, j] * crel[b, s, j]
+ * with the gradient that call returned (grad_dlog as it was passed to phk_loglik*), the float64 blocks and the coefficients
+ * of phk_prefold (params and crel share the element strides pstride_b, pstride_s; 0 broadcasts over the chunks).  The rounding of
+ * a float32 model is the same at every site of a row, so its effect on ll grows with the row length (about 1e-8 per site
+ * absolute: the reference's own float32 kernels lose the same); it is linear in the rounding residuals
+ * to first order, and the derivative it multiplies is the gradient the call has just computed.  What is left is the
+ * arithmetic's error, which does not add up coherently.  Not available to a no-gradient call. */
+int phk_ll_first_order(int device, int K, double* ll, const float* grad, int grad_dlog, const double* params, const double* crel,
+                       int64_t pstride_b, int64_t pstride_s, int64_t B, int64_t S, void* stream);
+
+/* phk_loglik for a float32 kernel object with the blocks' pre-folded factors (phk_prefold): ``prefold`` is laid out like
+ * ``params`` with five rows per block instead of seven (element strides pstride_b / 7 * 5, pstride_s / 7 * 5).  Same outputs,
+ * same flags; gradients are with respect to the rows of ``params`` as ever. */
+int phk_loglik_prefolded(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s, const float* prefold,
+                         const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad, int grad_dlog,
+                         void* stream);
 
 /* Particle -> PSMCParams for a whole population in one launch, float64, with its Jacobian.
  * Replaces, for B particles at once: MCMCParams.to_dm (src/phlash/params.py:94-127),
@@ -190,8 +225,15 @@ int phk_set_rescale_interval(phk_handle* h, int nrm);
 /* With nrm > 1 the forward kernel raises a sticky flag when a rescale finds the total mass below
  * 2^-64 (float) / 2^-600 (double), i.e. the parameters are extreme enough that the unscaled sites in
  * between could have lost precision.  Reads (and clears) the flag; synchronises with the work
- * enqueued before.  The Python host re-evaluates such a call with nrm = 1. */
+ * enqueued before.  The Python host re-evaluates such a call with nrm = 1.
+ * The same word carries two failure bits: a chunk index outside [0, N) (returns PHK_EINVAL) and, round 6, a kernel
+ * loop that ran out of its iteration budget (returns PHK_EOVERRUN; the message names kernel, sequence and block). */
 int phk_underflow_risk(phk_handle* h, int* flag);
+/* Test hook: scale the iteration budgets the kernels of this handle are given (default 1 / 1; the budget is twice the
+ * row's block count, an upper bound on the iterations any loop of a kernel can legitimately make).  kernels: bit 0 forward
+ * kernel, bit 1 backward kernel, bit 2 beta scan.  A scale below ~1/2 makes a healthy evaluation overrun, which is how
+ * tests/test_plans_and_modes.py exercises the PHK_EOVERRUN path. */
+int phk_set_loop_budget_scale(phk_handle* h, int kernels, int num, int den);
 /* The same flag word handed over WITHOUT a host synchronisation: a one-thread kernel on `stream`
  * writes dst[0] = 1.0 if the underflow-risk bit is set (else 0.0), dst[1] = 1.0 if a chunk index was
  * outside [0, N) (else 0.0) -- `dst` is a device array of two doubles -- and clears the word.  The

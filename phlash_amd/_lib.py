@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PHK_LIB (developer A/B builds only) may point at another build of the same library
 LIB_PATH = os.environ.get("PHK_LIB") or os.path.join(_HERE, "libphlash_hip.so")
 
-PHK_OK, PHK_EINVAL, PHK_ENOMEM, PHK_EHIP, PHK_EUNSUPPORTED = 0, 1, 2, 3, 4
+PHK_OK, PHK_EINVAL, PHK_ENOMEM, PHK_EHIP, PHK_EUNSUPPORTED, PHK_EOVERRUN = 0, 1, 2, 3, 4, 5
 
 # every symbol include/phlash_hip.h declares: (restype, argtypes)
 _vp, _i, _i64, _dp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)
@@ -26,6 +26,9 @@ SIGNATURES = {
     "phk_create": (_i, [ctypes.POINTER(_vp), _i, _vp, _i64, _i64, _i, _i, _i]),
     "phk_destroy": (_i, [_vp]),
     "phk_loglik": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
+    "phk_prefold": (_i, [_i, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "phk_ll_first_order": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "phk_loglik_prefolded": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i, _vp]),
     "phk_param_map": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.c_double, _vp, _i64, _vp, _vp, _vp]),
     "phk_param_map_rounded": (_i, [_i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.c_double, _vp, _i64, _vp, _vp, _vp, _vp]),
     "phk_reduce_chunks": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
@@ -42,6 +45,7 @@ SIGNATURES = {
     "phk_underflow_risk": (_i, [_vp, _ip]),
     "phk_take_flags_async": (_i, [_vp, _vp, _vp]),
     "phk_set_deterministic": (_i, [_vp, _i]),
+    "phk_set_loop_budget_scale": (_i, [_vp, _i, _i, _i]),
     "phk_set_autotune": (_i, [_vp, _i]),
     "phk_set_backward_mode": (_i, [_vp, _i]),
     "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),
@@ -59,6 +63,22 @@ SIGNATURES = {
 
 class HipError(RuntimeError):
     """A HIP runtime failure inside the library (the reference raises CudaError, gpu.py:23-32)."""
+
+
+class KernelOverrun(HipError):
+    """A kernel loop ran out of the iteration budget the host derived from the row length (PHK_EOVERRUN): the kernel returned
+    early instead of spinning, the evaluation is invalid.  The message names kernel, sequence and block."""
+
+
+OVERRUN_WEIGHT = 4096.0  # weight of the overrun bit in the second flag slot of the stream-ordered hand-over (take_flags_kernel)
+
+
+def check_failure_slot(bad: float, what: str):
+    """The second flag slot of a stream-ordered hand-over (possibly summed over ranks): chunk indices out of range count 1
+    each, kernels out of their loop budget ``OVERRUN_WEIGHT`` each."""
+    if bad >= OVERRUN_WEIGHT:
+        raise KernelOverrun(f"a kernel loop ran out of its iteration budget ({what}): the evaluation is invalid")
+    assert bad == 0, f"a chunk index was outside [0, N) ({what})"
 
 
 _lock = threading.Lock()
@@ -97,4 +117,6 @@ def check(rc: int):
         raise MemoryError(msg)  # gpu.py:117-124
     if rc == PHK_EUNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == PHK_EOVERRUN:
+        raise KernelOverrun(msg)
     raise HipError(msg)

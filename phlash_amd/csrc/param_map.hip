@@ -309,7 +309,9 @@ __global__ __launch_bounds__(RC_NT) void reduce_chunks_kernel(const double* __re
         if (t == 0) fw = flags ? atomicExch(flags, 0) : 0;
         __syncthreads();
         const int w = fw;
-        for (int i = t; i < 1 + J; i += RC_NT) row[i] = i == 0 ? ((w & 1) ? 1.0 : 0.0) : (i == 1 ? ((w & 2) ? 1.0 : 0.0) : 0.0);
+        // (bit 2 -- a loop out of its iteration budget, psmc_kernels.hip FLAG_OVERRUN -- rides in the second slot with the weight 4096)
+        for (int i = t; i < 1 + J; i += RC_NT)
+            row[i] = i == 0 ? ((w & 1) ? 1.0 : 0.0) : (i == 1 ? ((w & 2) ? 1.0 : 0.0) + ((w & 4) ? 4096.0 : 0.0) : 0.0);
         return;
     }
     // gradient: lane j of part p adds chunks p, p + parts, ...; the parts are then added in part order
@@ -501,6 +503,93 @@ __global__ __launch_bounds__(128) void afs_term_kernel(AFArgs A) {
 hipError_t launch_afs_term(const AFArgs& a, hipStream_t st) {
     if (a.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(afs_term_kernel, dim3((unsigned)a.B), dim3(128), 0, st, a);
+    return hipGetLastError();
+}
+
+// One thread per (block, state): the float32 rounding of the seven rows, and the float32 kernels' pre-folded factors.
+// The float32 kernels run on the model written with hom emission 1 (psmc_kernels.hip, "Folded model"): (b, d, v) <- emis0 .* (b, d, v)
+// and emission rows 1, emis1 / emis0, 1 / emis0.  Formed inside the kernels from the float32-rounded rows, every folded factor
+// carries three roundings (the factor, emis0, their product) that are the same at every site of a row; formed here in float64
+// and rounded once it carries one -- the rounding any float32 parameter has.
+// crel (optional, [n, 7, K] float64): what the rounding to float32 did to the MODEL, as coefficients of a first-order correction of
+// the log-likelihood.  Whatever the kernels compute, they compute for the model with factors q_eff = fl(q) instead of q, and to first
+// order  ll(q) - ll(q_eff) = sum_q (d ll / d log q) (q - q_eff) / q.  The factors of the folded model are b' = emis0 b, d', v', u,
+// the ratio rows emis1 / emis0 and 1 / emis0, and pi; their log-derivatives are linear in the rows the gradient kernel returns:
+// b d ll/d b etc., mass(het) = emis1 d ll/d emis1, mass(hom) = emis0 d ll/d emis0, and mass(missing) = b g_b + d g_d + v g_v -
+// mass(hom) - mass(het) (every site's posterior mass is the sum of the three products, state by state).  Collected per caller row r:
+//     ll(q) - ll(q_eff)  =  sum_{r, k} theta_{r,k} (d ll / d theta_{r,k}) crel_{r,k}  +  O(eps^2 L)
+// (phk_ll_first_order applies it).  The error that is left is the arithmetic's, which does not add up coherently along a row.
+__global__ void prefold_kernel(int K, const double* __restrict__ params, int64_t n, float* __restrict__ p32, float* __restrict__ pf,
+                               double* __restrict__ crel) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * K) return;
+    const int64_t q = idx / K;
+    const int k = (int)(idx - q * K);
+    const double* p = params + q * 7 * K;
+    float* o = p32 + q * 7 * K;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) o[r * K + k] = (float)p[r * K + k];
+    const double e0 = p[4 * K + k], e1 = p[5 * K + k];
+    float* f = pf + q * 5 * K;
+    const double fb = e0 * p[0 * K + k], fd = e0 * p[1 * K + k], fv = e0 * p[3 * K + k];
+    // (a block whose float32 emis0 is too small to fold is not folded by the kernels, whatever stands here: Lane::emissions_foldable)
+    const double rh = e0 > 0.0 ? e1 / e0 : 1.0, rm = e0 > 0.0 ? 1.0 / e0 : 1.0;
+    f[0 * K + k] = (float)fb;
+    f[1 * K + k] = (float)fd;
+    f[2 * K + k] = (float)fv;
+    f[3 * K + k] = (float)rh;
+    f[4 * K + k] = (float)rm;
+    if (crel == nullptr) return;
+    // relative residual of one rounding (0 for a zero, which float32 keeps exactly)
+    auto res = [](double x) { return x != 0.0 ? (x - (double)(float)x) / x : 0.0; };
+    bool folds = true;  // the kernels' own test (Lane::emissions_foldable): every float32 emis0 of the block above 2^-64
+    for (int j = 0; j < K; ++j) folds = folds && (float)p[4 * K + j] > 0x1p-64f;
+    double* c = crel + q * 7 * K;
+    if (folds) {
+        const double em = res(rm);
+        c[0 * K + k] = res(fb) + em;
+        c[1 * K + k] = res(fd) + em;
+        c[2 * K + k] = res(p[2 * K + k]);
+        c[3 * K + k] = res(fv) + em;
+        c[4 * K + k] = -em;
+        c[5 * K + k] = res(rh) - em;
+        c[6 * K + k] = res(p[6 * K + k]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) c[r * K + k] = res(p[r * K + k]);
+    }
+}
+
+hipError_t launch_prefold(int K, const double* params, int64_t n, float* params_f32, float* prefold_f32, double* crel, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t total = n * K;
+    hipLaunchKernelGGL(prefold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, K, params, n, params_f32, prefold_f32, crel);
+    return hipGetLastError();
+}
+
+// ll[b, s] += sum_j theta[b(,s), j] g[b, s, j] crel[b(,s), j]   (g = d ll / d theta, or theta d ll / d theta if dlog): one thread per sequence
+__global__ void ll_first_order_kernel(double* __restrict__ ll, const float* __restrict__ g, const double* __restrict__ params,
+                                      const double* __restrict__ crel, int64_t stride_b, int64_t stride_s, int64_t B, int64_t S, int J, int dlog) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * S) return;
+    const int64_t b = idx / S, s = idx - b * S;
+    const float* gr = g + idx * J;
+    const double* th = params + b * stride_b + s * stride_s;
+    const double* cr = crel + b * stride_b + s * stride_s;
+    double acc = 0.0;
+    for (int j = 0; j < J; ++j) {
+        const double c = cr[j];
+        if (c != 0.0) acc = fma((double)gr[j] * (dlog ? 1.0 : th[j]), c, acc);
+    }
+    ll[idx] += acc;
+}
+
+hipError_t launch_ll_first_order(double* ll, const float* g, const double* params, const double* crel, int64_t stride_b, int64_t stride_s,
+                                 int64_t B, int64_t S, int K, int dlog, hipStream_t st) {
+    const int64_t n = B * S;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ll_first_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ll, g, params, crel, stride_b, stride_s, B, S,
+                       7 * K, dlog);
     return hipGetLastError();
 }
 

@@ -152,6 +152,7 @@ struct phk_handle {
     hipStream_t side = nullptr;  // second stream of the segmented plan
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
+    int budget_num[3] = {1, 1, 1}, budget_den[3] = {1, 1, 1};  // phk_set_loop_budget_scale (tests): forward kernel, backward kernel, beta scan
     int poison = 0;  // diagnostic: fill the scratch buffers with this byte before every launch sequence (PHK_POISON=255: NaN patterns)
     std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch since the last timing query
     int n_launches = 0;          // launches recorded since the last query
@@ -370,7 +371,7 @@ int build_dense_ops(phk_handle* h, phk::KArgs* a, hipStream_t st) {
     float* f = (float*)h->ops.p;
     float* b = f + nblk * phk::DENSE_OPS_FLOATS;
     hipLaunchKernelGGL(phk::dense_ops_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const float*)a->params, a->pstride_b, a->pstride_s,
-                       a->pstride_s != 0 ? a->S : (int64_t)1, f, b);
+                       a->pstride_s != 0 ? a->S : (int64_t)1, f, b, a->prefold, a->pfstride_b, a->pfstride_s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PHK_EHIP, "dense operator table launch: %s", hipGetErrorString(e));
     a->ops_f = f;
@@ -410,6 +411,17 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     const int64_t nseq = a.B * a.S;
     hipError_t e;
     a.seg_blocks = seg_blocks(plan.T);
+    {   // Iteration budgets (KArgs::loop_budget): twice what a healthy wave needs, from the row length alone.  The forward kernel
+        // and the beta scan make one outer iteration per 64-site piece (the ragged pieces at the warm-up boundary and the row's
+        // end a few more: one per block / word), a serial sweep one per block, a unit of the segment sweep one per block of its
+        // segments (unit 0: every segment up to the one holding the warm-up boundary).
+        const int64_t nblk = (h->L + plan.T - 1) / plan.T, npieces = h->Lw / 4, G = a.seg_blocks;
+        const int64_t segW = a.W > 0 ? ((a.W - 1) / plan.T) / G : 0;
+        const int64_t need[4] = {npieces + 2 * (64 / plan.T) + 8, nblk + 8, npieces + 16, G * (segW + 1) + 8};
+        const int scale_of[4] = {0, 1, 2, 1};
+        for (int i = 0; i < 4; ++i)
+            a.loop_budget[i] = (int32_t)std::min<int64_t>(2 * need[i] * h->budget_num[scale_of[i]] / h->budget_den[scale_of[i]], INT32_MAX);
+    }
     if (!want_grad) {
         e = l.fwd(plan.R1 && !plan.segmented ? plan.R1 : plan.R, plan.T, h->nrm, false, a, nt, st);
         if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R, plan.T, hipGetErrorString(e));
@@ -754,7 +766,7 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
     if (const char* env = std::getenv("PHK_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
     if (const char* env = std::getenv("PHK_POISON")) h->poison = std::atoi(env);
-    if (h->risk.ensure(sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, sizeof(int)) != hipSuccess) {
+    if (h->risk.ensure(4 * sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, 4 * sizeof(int)) != hipSuccess) {  // flag word + (kernel, sequence, block) of an overrun
         delete h;
         return fail(PHK_ENOMEM, "could not allocate the underflow flag");
     }
@@ -931,14 +943,20 @@ int phk_underflow_risk(phk_handle* h, int* flag) {
     HIP_TRY(hipSetDevice(h->device));
     // the flag word is written by kernels on the stream of the last phk_loglik (pool streams of
     // PyTorch are non-blocking: the null stream would not wait for them), so read it behind that stream
-    int word = 0;
-    HIP_TRY(hipMemcpyAsync(&word, h->risk.p, sizeof(int), hipMemcpyDeviceToHost, h->last_stream));
+    int rec[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(rec, h->risk.p, sizeof(rec), hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(hipStreamSynchronize(h->last_stream));
+    const int word = rec[0];
     if (word) {
-        HIP_TRY(hipMemsetAsync(h->risk.p, 0, sizeof(int), h->last_stream));
+        HIP_TRY(hipMemsetAsync(h->risk.p, 0, sizeof(rec), h->last_stream));
         HIP_TRY(hipStreamSynchronize(h->last_stream));
     }
     *flag = (word & phk::FLAG_UNDERFLOW) ? 1 : 0;
+    if (word & phk::FLAG_OVERRUN) {
+        static const char* const names[] = {"?", "fwd_kernel", "bwd_kernel (serial sweep)", "bwd_kernel (segment sweep)", "bscan_kernel"};
+        return fail(PHK_EOVERRUN, "%s ran out of its loop budget at sequence %d, block/word %d (L=%lld): the call's results are invalid",
+                    names[rec[1] >= 1 && rec[1] <= 4 ? rec[1] : 0], rec[2], rec[3], (long long)h->L);
+    }
     if (word & phk::FLAG_BAD_INDEX) return fail(PHK_EINVAL, "a chunk index passed to phk_loglik was outside [0, N=%lld)", (long long)h->N);
     return PHK_OK;
 }
@@ -948,6 +966,18 @@ int phk_take_flags_async(phk_handle* h, double* dst, void* stream) {
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(phk::take_flags_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)h->risk.p, dst);
     HIP_TRY(hipGetLastError());
+    return PHK_OK;
+}
+
+int phk_set_loop_budget_scale(phk_handle* h, int kernels, int num, int den) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (num < 0 || den <= 0) return fail(PHK_EINVAL, "scale must be num / den with num >= 0, den > 0");
+    for (int i = 0; i < 3; ++i) {
+        if (kernels & (1 << i)) {
+            h->budget_num[i] = num;
+            h->budget_den[i] = den;
+        }
+    }
     return PHK_OK;
 }
 
@@ -1179,8 +1209,47 @@ int phk_svgd_step(int device, int64_t B, int D, const double* x, const double* g
     return PHK_OK;
 }
 
+int phk_ll_first_order(int device, int K, double* ll, const float* grad, int grad_dlog, const double* params, const double* crel,
+                       int64_t pstride_b, int64_t pstride_s, int64_t B, int64_t S, void* stream) {
+    if (K < 1 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [1, %d]", K, phk::PM_MAXK);
+    if (!ll || !grad || !params || !crel) return fail(PHK_EINVAL, "NULL argument");
+    if (B < 0 || S < 0) return fail(PHK_EINVAL, "B and S must be >= 0");
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_ll_first_order(ll, grad, params, crel, pstride_b, pstride_s, B, S, K, grad_dlog, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "first-order correction kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+int phk_prefold(int device, int K, const double* params, int64_t nblocks, float* params_f32, float* prefold_f32, double* crel, void* stream) {
+    if (K < 1 || K > phk::PM_MAXK) return fail(PHK_EUNSUPPORTED, "K=%d outside [1, %d]", K, phk::PM_MAXK);
+    if (!params || !params_f32 || !prefold_f32) return fail(PHK_EINVAL, "NULL argument");
+    if (nblocks < 0) return fail(PHK_EINVAL, "nblocks must be >= 0");
+    if (nblocks == 0) return PHK_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = phk::launch_prefold(K, params, nblocks, params_f32, prefold_f32, crel, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PHK_EHIP, "prefold kernel launch: %s", hipGetErrorString(e));
+    return PHK_OK;
+}
+
+static int loglik_impl(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s, const float* prefold,
+                       const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad, int grad_dlog, void* stream);
+
 int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s, const int64_t* inds,
                int64_t B, int64_t S, int64_t W, double* ll, void* grad, int grad_dlog, void* stream) {
+    return loglik_impl(h, params, pstride_b, pstride_s, nullptr, inds, B, S, W, ll, grad, grad_dlog, stream);
+}
+
+int phk_loglik_prefolded(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s, const float* prefold,
+                         const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad, int grad_dlog, void* stream) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+    if (!prefold) return fail(PHK_EINVAL, "prefold is NULL (phk_loglik takes blocks without pre-folded factors)");
+    if (h->dbl) return fail(PHK_EINVAL, "pre-folded factors belong to the float32 kernels (the float64 kernels do not fold)");
+    if (pstride_b % 7 != 0 || pstride_s % 7 != 0) return fail(PHK_EINVAL, "parameter strides must be multiples of 7 (whole [7, K] blocks)");
+    return loglik_impl(h, params, pstride_b, pstride_s, prefold, inds, B, S, W, ll, grad, grad_dlog, stream);
+}
+
+static int loglik_impl(phk_handle* h, const void* params, int64_t pstride_b, int64_t pstride_s, const float* prefold,
+                       const int64_t* inds, int64_t B, int64_t S, int64_t W, double* ll, void* grad, int grad_dlog, void* stream) {
     if (!h) return fail(PHK_EINVAL, "handle is NULL");
     if (!params || !inds || !ll) return fail(PHK_EINVAL, "params, inds and ll must be non-NULL device pointers");
     if (B < 0 || S < 0) return fail(PHK_EINVAL, "B and S must be >= 0");
@@ -1245,6 +1314,11 @@ int phk_loglik(phk_handle* h, const void* params, int64_t pstride_b, int64_t pst
         a.N = h->N;
         a.part = h->part.p;
         a.ops_f = a.ops_b = nullptr;  // build_dense_ops sets them where the plan runs a one-state-per-lane kernel
+        // the pre-folded blocks are laid out like the parameter blocks, five rows instead of seven
+        for (int i = 0; i < 4; ++i) a.loop_budget[i] = INT32_MAX;  // enqueue() sets the plan's values
+        a.pfstride_b = pstride_b / 7 * 5;
+        a.pfstride_s = pstride_s / 7 * 5;
+        a.prefold = prefold ? prefold + (b0 * a.pfstride_b + s0 * a.pfstride_s) : nullptr;
         return a;
     };
 

@@ -409,20 +409,36 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
         for (int i = 0; i < EROW; ++i) ok = ok && etab[i] > (real)RATIO_MIN_EMIS0;
         return g.sum(ok ? real(0) : real(1)) == real(0);
     }
-    __device__ __forceinline__ void fold_emissions() {
+    // pf (round 6, KArgs::prefold): this lane's slice of the sequence's PRE-FOLDED block [5, K] -- rows fl(emis0 b),
+    // fl(emis0 d), fl(emis0 v), fl(emis1 / emis0), fl(1 / emis0), formed in float64 from the float64 parameters and
+    // rounded ONCE (phk_prefold).  Folding here, from the float32-rounded factors, rounds each of b, d, v three times
+    // (b, emis0, their product), and the error of a factor is the same at every site: it adds up along the row.
+    __device__ __forceinline__ void fold_emissions(const real* pf) {
         real* t = const_cast<real*>(etab);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             const V e0 = ((const V*)t)[h];
             const V e1 = ((const V*)(t + EROW))[h];
-            b[h] = b[h] * e0;
-            d[h] = d[h] * e0;
-            v[h] = v[h] * e0;
+            if (pf == nullptr) {
+                b[h] = b[h] * e0;
+                d[h] = d[h] * e0;
+                v[h] = v[h] * e0;
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                const int i = SPLIT ? h + c * NP : 2 * h + c;  // state of the lane in half c of pair h
                 t[0 * EROW + 2 * h + c] = real(1);
-                t[1 * EROW + 2 * h + c] = (real)((double)e1[c] / (double)e0[c]);
-                t[2 * EROW + 2 * h + c] = (real)(1.0 / (double)e0[c]);
+                if (pf != nullptr) {
+                    const bool ok = i < SPL;
+                    b[h][c] = ok ? pf[0 * K + i] : real(0);
+                    d[h][c] = ok ? pf[1 * K + i] : real(0);
+                    v[h][c] = ok ? pf[2 * K + i] : real(0);
+                    t[1 * EROW + 2 * h + c] = ok ? pf[3 * K + i] : real(1);
+                    t[2 * EROW + 2 * h + c] = ok ? pf[4 * K + i] : real(1);
+                } else {
+                    t[1 * EROW + 2 * h + c] = (real)((double)e1[c] / (double)e0[c]);
+                    t[2 * EROW + 2 * h + c] = (real)(1.0 / (double)e0[c]);
+                }
             }
         }
     }
@@ -431,10 +447,10 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // kernel's alpha and the sweep's beta belong to two HMMs that differ by one rounding per factor, a difference
     // that is the same at every site and adds up along the row (60,000 sites: sum(alpha .* beta) drifts 6e-4 from 1
     // and takes every gradient row with it).  float64 kernels keep their emissions in the table.
-    __device__ __forceinline__ bool try_fold() {
+    __device__ __forceinline__ bool try_fold(const real* pf = nullptr) {
         if constexpr (sizeof(real) == 4 && PHK_FOLD != 0) {
             const bool ok = emissions_foldable();
-            if (ok) fold_emissions();
+            if (ok) fold_emissions(pf);
             return ok;
         } else {
             return false;
@@ -946,13 +962,42 @@ struct KArgs {
     // [9 powers M_h^1..8, M_h^16][lane 16][slot 16] floats, forward form and beta-scan form; null where those kernels are not used
     const float* ops_f;
     const float* ops_b;
+    // pre-folded factors of every parameter block (float32 kernels; phk_prefold / phk_loglik_prefolded): [B, S|1, 5, K]
+    // with the element strides below, or null (the kernels then fold the float32 rows themselves: Lane::fold_emissions)
+    const float* prefold;
+    int64_t pfstride_b, pfstride_s;
+    // Iteration budget of every loop whose trip count derives from these arguments (round 6): an upper bound, computed on the
+    // host from the row length, on the loop iterations one wave of each kernel can legitimately make.  A kernel that exhausts it
+    // raises FLAG_OVERRUN, records where, and returns -- so that no inconsistency of the arguments (or of this file) can make a
+    // wave spin until the watchdog takes the GPU away.  [0] forward kernel (outer iterations: one per 64-site piece or per
+    // block of a ragged piece), [1] serial sweep (blocks), [2] beta scan (pieces / words), [3] one unit of the segment sweep (blocks).
+    int32_t loop_budget[4];
 };
+
+// this sequence's pre-folded block (lane slice added by the caller), or null
+template <typename real>
+__device__ __forceinline__ const real* prefold_block(const KArgs& A, int64_t bb, int64_t ss) {
+    if constexpr (sizeof(real) == 4) return A.prefold != nullptr ? (const real*)A.prefold + bb * A.pfstride_b + ss * A.pfstride_s : nullptr;
+    else return nullptr;
+}
 constexpr int DENSE_NPOW = 9;
 constexpr int DENSE_OPS_FLOATS = DENSE_NPOW * 256;  // per parameter block and form
 
 // bits of the sticky device flag word (KArgs::risk)
 constexpr int FLAG_UNDERFLOW = 1;  // a rescale found the mass below 2^RISK_EXP (see below)
 constexpr int FLAG_BAD_INDEX = 2;  // a chunk index outside [0, N): the row was clamped to 0, the result is garbage
+constexpr int FLAG_OVERRUN = 4;    // a block / piece loop ran out of the iteration budget the host gave it (KArgs::loop_budget): the kernel
+                                   // returned early, the call's results are garbage; risk[1..3] name the kernel, sequence and block
+
+// first reporter records (kernel id, sequence, block or word) behind the flag word
+__device__ __forceinline__ void report_overrun(const KArgs& A, int kernel_id, int64_t seq, int where) {
+    if (A.risk == nullptr) return;
+    if ((atomicOr(A.risk, FLAG_OVERRUN) & FLAG_OVERRUN) == 0) {
+        A.risk[1] = kernel_id;
+        A.risk[2] = (int)seq;
+        A.risk[3] = where;
+    }
+}
 
 // row of the observation matrix for chunk ss, range-checked (gpu.py:197-199 asserts this on the host;
 // here the indices live on the device, so the check does too)
@@ -1163,7 +1208,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     V a[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
-    const bool fold_seq = lane.try_fold();  // (float32: the folded model, see Lane::try_fold)
+    const real* pfb = prefold_block<real>(A, bb, ss);
+    const bool fold_seq = lane.try_fold(pfb != nullptr ? pfb + rank * L::SPL : nullptr);  // (float32: the folded model, see Lane::try_fold)
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
     if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
     const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
@@ -1531,7 +1577,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
             ebp += (int64_t)BPC * nseq;
         }
     };
+    int budget = A.loop_budget[0];  // (see KArgs::loop_budget; wave-uniform)
     for (int pc = 0; blk < nblk; pc += PPB) {
+     if (__builtin_expect(--budget < 0, 0)) break;
      if constexpr (LEAN && FOLD) {
          // uni2 waves read both rows by scalar loads for as long as the pieces are lean (see the one-state-per-lane
          // loop below: no wait for the checkpoint stores; each piece is landed before the next is requested)
@@ -1546,8 +1594,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                  fold_piece((uint64_t)cA.x | ((uint64_t)cA.y << 32), (uint64_t)cA.z | ((uint64_t)cA.w << 32),
                             (uint64_t)cB.x | ((uint64_t)cB.y << 32), (uint64_t)cB.z | ((uint64_t)cB.w << 32));
                  ++pc;
-             } while (lean_piece(blk));
-             if (blk >= nblk) break;
+             } while (lean_piece(blk) && --budget >= 0);
+             if (blk >= nblk || budget < 0) break;
              pnext = pieces[pc < npieces ? pc : npieces - 1];
          }
      }
@@ -1568,8 +1616,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
                  snext = sp[pc + 1 < npieces ? pc + 1 : npieces - 1];
                  uni_piece((uint64_t)sc.x | ((uint64_t)sc.y << 32), (uint64_t)sc.z | ((uint64_t)sc.w << 32));
                  ++pc;
-             } while (lean_piece(blk));
-             if (blk >= nblk) break;
+             } while (lean_piece(blk) && --budget >= 0);
+             if (blk >= nblk || budget < 0) break;
              pnext = pieces[pc < npieces ? pc : npieces - 1];
          }
      }
@@ -1718,6 +1766,10 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
       }
      }
     }
+    if (__builtin_expect(budget < 0, 0)) {  // out of its iteration budget: flag, record, leave (the call has failed)
+        report_overrun(A, 1, seq, blk);
+        return;
+    }
     const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
     if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
         (ex_slack < 0 || !(cend > 0.0)))
@@ -1847,7 +1899,8 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     // exactly 1: the same bits).  The flag goes to aux for the segment sweep's finalize.
     // Kernels without that body (16-site blocks, per-site rescaling, 16 states per lane) run on the folded model all the
     // same (Lane::try_fold) and book the hom mass directly; only the conversion at the end differs (aux.folded = 2).
-    const bool folded = lane.try_fold();  // (per sequence)
+    const real* pfb = prefold_block<real>(A, bb, ss);
+    const bool folded = lane.try_fold(pfb != nullptr ? pfb + rank * SPL : nullptr);  // (per sequence)
     const int g0code = (SFOLD && folded) ? 2 : 0;
     const bool wave_folded = SFOLD && __all(folded) != 0;
     // HREG (round 6): what a het site needs in the hot body -- its ratio row and the row its posterior mass is booked in --
@@ -2038,8 +2091,14 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
     const bool wave_steep = HOT_V2 && __any(A.aux[seq].eb_min < HOT_MIN_EXP);
 #endif
     int blk = blk_hi - 1;
+    int budget = A.loop_budget[SEG ? 3 : 1];  // blocks this wave may still sweep (see KArgs::loop_budget)
     while (blk >= blk_lo) {
+        if (__builtin_expect(budget <= 0, 0)) {
+            report_overrun(A, SEG ? 3 : 2, seq, blk);
+            return;
+        }
         if (!HOT || wave_steep || (HREG && !wave_folded) || blk == blkW || blk == blk_part) {
+            --budget;
             const int64_t t0 = (int64_t)blk * T;
             V al[T + 1][NP];  // al[i] = alpha entering site i of the block; al[ns] = alpha leaving it
             real sc[T / NRM];
@@ -2128,6 +2187,8 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
                     if (blk - left + 1 > stop) stop = blk - left + 1;
                 }
             }
+            if (blk - stop + 1 > budget) stop = blk - budget + 1;  // (the budget bounds the run: no test inside the block loop)
+            budget -= blk - stop + 1;
             const int first = blk;
             for (; blk >= stop; --blk) {
                 int e_fwd;
@@ -2662,7 +2723,8 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     V pi[NP], beta[NP];
     lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
               (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
-    const bool fold_seq = lane.try_fold();  // (float32: the folded model, see Lane::try_fold)
+    const real* pfb = prefold_block<real>(A, bb, ss);
+    const bool fold_seq = lane.try_fold(pfb != nullptr ? pfb + rank * L::SPL : nullptr);  // (float32: the folded model, see Lane::try_fold)
     constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
     if constexpr (DENSE) lane.template load_dense<true>(A.ops_b + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
 #pragma unroll
@@ -2796,7 +2858,9 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
         --sb;
         w_store -= seg_words;
     };
+    int budget = A.loop_budget[2];  // (see KArgs::loop_budget)
     for (; w >= 0; --pc) {
+      if (__builtin_expect(--budget < 0, 0)) break;
       if constexpr (DENSE && PHK_DENSE_LEAN != 0 && PHK_DENSE_UNI_SCAN != 0 && PHK_UNI_SLOAD != 0) {
           // A wave whose sequences share their observation row reads it by scalar loads from here to the row's start
           // (every piece left of the one holding the last word is four whole words): see fwd_kernel.  The four words
@@ -2823,7 +2887,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
                       }
                   }
                   --pc;
-              } while (w >= 0);
+              } while (w >= 0 && --budget >= 0);
               break;
           }
       }
@@ -2903,6 +2967,10 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
 
       }
     }
+    if (__builtin_expect(budget < 0, 0)) {
+        report_overrun(A, 4, seq, w);
+        return;
+    }
     if constexpr (DENSE) {  // the scan's own underflow flag (its seeds feed the segment sweep; see fwd_kernel for the thresholds)
         if (active && rank == 0 && A.risk != nullptr && f_slack < 0) atomicOr(A.risk, FLAG_UNDERFLOW);
     }
@@ -2960,8 +3028,12 @@ __global__ void grad_unfold_kernel(KArgs A, int K) {
     const double vb = (double)out[0 * K + k], vd = (double)out[1 * K + k], vu = (double)out[2 * K + k], vv = (double)out[3 * K + k];
     const double vm = (double)out[4 * K + k], v1 = (double)out[5 * K + k];
     // folded factors exactly as the kernels formed them (float products)
-    const double lb = vb * (double)(p[0 * K + k] * p[4 * K + k]), ld = vd * (double)(p[1 * K + k] * p[4 * K + k]);
-    const double lv = vv * (double)(p[3 * K + k] * p[4 * K + k]);
+    // (... or took from the pre-folded block)
+    const real* pf = prefold_block<real>(A, bb, ss);
+    const double fb = pf != nullptr ? (double)pf[0 * K + k] : (double)(p[0 * K + k] * p[4 * K + k]);
+    const double fd = pf != nullptr ? (double)pf[1 * K + k] : (double)(p[1 * K + k] * p[4 * K + k]);
+    const double fv = pf != nullptr ? (double)pf[2 * K + k] : (double)(p[3 * K + k] * p[4 * K + k]);
+    const double lb = vb * fb, ld = vd * fd, lv = vv * fv;
     const double mhom = A.aux[seq].folded == 1 ? lb + ld + lv - v1 - vm : vm;  // (2: the hom mass was booked directly)
     out[0 * K + k] = (real)(dl ? lb : vb * e0);
     out[1 * K + k] = (real)(dl ? ld : vd * e0);
@@ -2976,12 +3048,14 @@ __global__ void grad_unfold_kernel(KArgs A, int K) {
 // (a plain, non-template kernel: emitted only in the translation unit that defines PHK_WITH_PACK)
 // ---------------------------------------------------------------------------------------------
 #ifdef PHK_WITH_PACK
+constexpr double FLAG_OVERRUN_WEIGHT = 4096.0;
 // stream-ordered hand-over of the flag word, one double per bit (so that the bits survive the SUM
 // all-reduce of the float64 buffer they ride in): dst[0] = underflow risk, dst[1] = bad index; flags = 0
 __global__ void take_flags_kernel(int* flags, double* dst) {
     const int w = atomicExch(flags, 0);
     dst[0] = (w & FLAG_UNDERFLOW) ? 1.0 : 0.0;
-    dst[1] = (w & FLAG_BAD_INDEX) ? 1.0 : 0.0;
+    // (a loop that ran out of its budget rides in the second slot with a weight of its own: sums over ranks stay decodable)
+    dst[1] = ((w & FLAG_BAD_INDEX) ? 1.0 : 0.0) + ((w & FLAG_OVERRUN) ? FLAG_OVERRUN_WEIGHT : 0.0);
 }
 
 // Dense hom-run operators for the one-state-per-lane kernels (K = 16, float32): one workgroup per parameter block,
@@ -2992,7 +3066,8 @@ __global__ void take_flags_kernel(int* flags, double* dst) {
 //   ops_f[blk][n][i][j] = (M_h^n)[j][i]   (forward kernel: lane i holds column i)
 //   ops_b[blk][n][i][j] = (M_h^n)[i][j]   (beta scan: lane i holds row i)
 __global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict__ params, int64_t pstride_b, int64_t pstride_s,
-                                                        int64_t S_blocks, float* __restrict__ ops_f, float* __restrict__ ops_b) {
+                                                        int64_t S_blocks, float* __restrict__ ops_f, float* __restrict__ ops_b,
+                                                        const float* __restrict__ prefold, int64_t pfstride_b, int64_t pfstride_s) {
     __shared__ double Mx[5][16][17];  // M, M^2, M^3, M^4, M^8
     const int64_t q = blockIdx.x;
     const int64_t bb = q / S_blocks, ss = q - bb * S_blocks;
@@ -3003,9 +3078,11 @@ __global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict_
     // folds -- Lane::try_fold -- so that dense and structured steps advance the same model)
     const float e0f = p[4 * 16 + c];
     const bool fold = PHK_FOLD != 0 && __syncthreads_and(e0f > RATIO_MIN_EMIS0);
-    const double bc = fold ? (double)(p[0 * 16 + c] * e0f) : (double)p[0 * 16 + c] * (double)e0f;
-    const double dc = fold ? (double)(p[1 * 16 + c] * e0f) : (double)p[1 * 16 + c] * (double)e0f;
-    const double vc = fold ? (double)(p[3 * 16 + c] * e0f) : (double)p[3 * 16 + c] * (double)e0f;
+    // (... or took pre-folded: the same bits the structured steps of the sequence run on)
+    const float* pf = prefold != nullptr ? prefold + bb * pfstride_b + ss * pfstride_s : nullptr;
+    const double bc = fold ? (pf ? (double)pf[0 * 16 + c] : (double)(p[0 * 16 + c] * e0f)) : (double)p[0 * 16 + c] * (double)e0f;
+    const double dc = fold ? (pf ? (double)pf[1 * 16 + c] : (double)(p[1 * 16 + c] * e0f)) : (double)p[1 * 16 + c] * (double)e0f;
+    const double vc = fold ? (pf ? (double)pf[2 * 16 + c] : (double)(p[3 * 16 + c] * e0f)) : (double)p[3 * 16 + c] * (double)e0f;
     const double m = r > c ? bc : (r == c ? dc : ur * vc);
     float* of = ops_f + q * DENSE_OPS_FLOATS;
     float* ob = ops_b + q * DENSE_OPS_FLOATS;

@@ -19,6 +19,12 @@ struct PMArgs {
     float* params_f32;      // [B, 7, K] the same block rounded to float32 (what the float32 kernels take), or null
 };
 hipError_t launch_param_map(const PMArgs& a, hipStream_t st);
+// params [n, 7, K] float64 -> the same block rounded to float32 + the float32 kernels' pre-folded factors [n, 5, K]
+// (rows fl(emis0 b), fl(emis0 d), fl(emis0 v), fl(emis1 / emis0), fl(1 / emis0): products and quotients in float64, rounded once)
+hipError_t launch_prefold(int K, const double* params, int64_t n, float* params_f32, float* prefold_f32, double* crel, hipStream_t st);
+// ll [B, S] += sum_j theta_j (d ll / d theta_j) crel_j: the first-order effect of the float32 rounding of the model, taken back
+hipError_t launch_ll_first_order(double* ll, const float* g, const double* params, const double* crel, int64_t stride_b, int64_t stride_s,
+                                 int64_t B, int64_t S, int K, int dlog, hipStream_t st);
 hipError_t launch_log_prior(int P, double alpha, double beta, const double* x, int64_t B, double* value, double* grad,
                             hipStream_t st);
 

@@ -36,6 +36,11 @@ class HipEngine:
         self.double_precision = bool(double_precision)
         self.device = torch.device("cuda", int(device))
         self.dtype = torch.float64 if double_precision else torch.float32
+        # float64 parameter blocks handed to a float32 kernel object are rounded together with their folded factors
+        # (``run``); False = round the rows only and let the kernels fold them, as a caller with float32 blocks gets it
+        self.prefold = True
+        # ... and a gradient call's ll is corrected to first order for what the rounding did to the model (phk_ll_first_order)
+        self.first_order = True
         self._h = ctypes.c_void_p()
         if isinstance(data, torch.Tensor) and data.is_cuda:
             # device-resident matrix: validate with torch (gpu.py:103-113), hand over the pointer
@@ -96,6 +101,11 @@ class HipEngine:
         assert buf.is_contiguous() and buf.dtype == torch.float64 and buf.shape == (B + 1, 1 + 7 * self.K)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(_lib.load().phk_reduce_chunks(self._h, ll.data_ptr(), g.data_ptr(), B, S, buf.data_ptr(), ctypes.c_void_p(stream)))
+
+    def set_loop_budget_scale(self, kernels: int = 7, num: int = 1, den: int = 1):
+        """Test hook (``phk_set_loop_budget_scale``): scale the iteration budgets of the forward kernel (bit 0), the backward
+        kernel (bit 1), the beta scan (bit 2)."""
+        _lib.check(_lib.load().phk_set_loop_budget_scale(self._h, int(kernels), int(num), int(den)))
 
     def set_deterministic(self, on: bool):
         _lib.check(_lib.load().phk_set_deterministic(self._h, int(bool(on))))
@@ -176,18 +186,39 @@ class HipEngine:
         B, Sp = params.shape[0], params.shape[1]
         S = inds.shape[0]
         assert Sp in (1, S)
-        p = params.to(self.dtype).contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        pf = None
+        if params.dtype == torch.float64 and not self.double_precision and self.prefold:
+            # float64 blocks for a float32 kernel object: one launch rounds them AND forms the folded factors the float32
+            # kernels run on in float64, rounded once (phk_prefold; the kernels would otherwise fold the rounded rows)
+            p64 = params.contiguous()
+            p = torch.empty(p64.shape, dtype=torch.float32, device=self.device)
+            pf = torch.empty((B, Sp, 5, self.K), dtype=torch.float32, device=self.device)
+            # (with a gradient: also the coefficients that take the first-order effect of the rounding out of ll afterwards)
+            crel = torch.empty(p64.shape, dtype=torch.float64, device=self.device) if (grad and self.first_order) else None
+            _lib.check(_lib.load().phk_prefold(self.device.index, self.K, p64.data_ptr(), B * Sp, p.data_ptr(), pf.data_ptr(),
+                                               crel.data_ptr() if crel is not None else None, ctypes.c_void_p(stream)))
+        else:
+            p = params.to(self.dtype).contiguous()
         inds = inds.contiguous()
         ll = torch.empty((B, S), dtype=torch.float64, device=self.device)
         g = torch.empty((B, S, 7, self.K), dtype=self.dtype, device=self.device) if grad else None
         stride_b = Sp * 7 * self.K
         stride_s = 7 * self.K if Sp == S else 0
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = _lib.load().phk_loglik(
-            self._h, p.data_ptr(), stride_b, stride_s, inds.data_ptr(), B, S, int(warmup),
-            ll.data_ptr(), g.data_ptr() if grad else None, int(bool(dlog)), ctypes.c_void_p(stream),
-        )
+        if pf is not None:
+            rc = _lib.load().phk_loglik_prefolded(
+                self._h, p.data_ptr(), stride_b, stride_s, pf.data_ptr(), inds.data_ptr(), B, S, int(warmup),
+                ll.data_ptr(), g.data_ptr() if grad else None, int(bool(dlog)), ctypes.c_void_p(stream),
+            )
+        else:
+            rc = _lib.load().phk_loglik(
+                self._h, p.data_ptr(), stride_b, stride_s, inds.data_ptr(), B, S, int(warmup),
+                ll.data_ptr(), g.data_ptr() if grad else None, int(bool(dlog)), ctypes.c_void_p(stream),
+            )
         _lib.check(rc)
+        if pf is not None and grad and crel is not None:
+            _lib.check(_lib.load().phk_ll_first_order(self.device.index, self.K, ll.data_ptr(), g.data_ptr(), int(bool(dlog)),
+                                                      p64.data_ptr(), crel.data_ptr(), stride_b, stride_s, B, S, ctypes.c_void_p(stream)))
         if grad and self.K_user != self.K:
             g = g[..., : self.K_user]
         return (ll, g) if grad else ll

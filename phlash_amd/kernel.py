@@ -20,6 +20,7 @@ import warnings
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import HipEngine
 from .params import PSMCParams
 from .size_history import DemographicModel
@@ -273,7 +274,7 @@ class PSMCKernel:
             self._flags = None
         elif also is not None:
             self.also_value = float(also)
-        assert bad == 0, f"a chunk index was outside [0, N={self.N})"
+        _lib.check_failure_slot(bad, f"N={self.N}")
         risk = under > 0
         if not collective:
             risk = self._eng.underflow_risk() or risk  # evaluations that did not go through take_flags_into
@@ -314,7 +315,7 @@ class PSMCKernel:
         slot, done = pending
         done.synchronize()
         under, bad, self.also_value = (float(v) for v in slot)
-        assert bad == 0, f"a chunk index was outside [0, N={self.N})"
+        _lib.check_failure_slot(bad, f"N={self.N}")
         if under > 0:
             warnings.warn("extreme HMM parameters: switching to per-site rescaling for this kernel object")
             self._eng.set_rescale_interval(1)

@@ -35,7 +35,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import parallel, step, svgd
+from . import _lib, parallel, step, svgd
 from .afs import bws_transform, fold_transform
 from .data import init_mcmc_data
 from .kernel import get_kernel
@@ -86,7 +86,7 @@ class _NoRows:
         else:
             under, bad = (float(v) for v in self._flags.cpu())
         self._flags = None
-        assert bad == 0, "a chunk index was out of range on another rank"
+        _lib.check_failure_slot(bad, "on another rank")
         return under > 0
 
     def switch_to_per_site_rescaling(self):  # (no engine here: the ranks that own rows switch theirs)
@@ -452,7 +452,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
         parallel.all_reduce_sum_(tot)
         e, under, bad = (float(v) for v in tot.cpu())  # synchronises; the same three numbers on every rank
         k_._flags = None
-        assert bad == 0, "a chunk index of the held-out rows was out of range"
+        _lib.check_failure_slot(bad, "held-out rows")
         if under > 0:  # extreme particles: once more with per-site rescaling, at once and in line
             k_.switch_to_per_site_rescaling()
             e = elpd(st0.particles)

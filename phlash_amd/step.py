@@ -4,8 +4,9 @@ in a fixed sequence of HIP launches.
 What ``jax.grad(log_density)`` under ``vmap`` is in the reference (src/phlash/mcmc.py:275-286 through
 model.py:24-73, params.py:33-127, transition.py:37-85) is here
 
-    phk_param_map_rounded   x [B, D] -> params [B, 7, K] (float64, and rounded to the kernels' float type) + Jacobian
-    phk_loglik              forward / backward kernels over the minibatch  -> ll [B, S], d ll / d params [B, S, 7, K]
+    phk_param_map           x [B, D] -> params [B, 7, K] (float64) + Jacobian
+    phk_prefold             (float32 kernels) the block rounded to float32 + its folded factors, formed in float64
+    phk_loglik_prefolded    forward / backward kernels over the minibatch  -> ll [B, S], d ll / d params [B, S, 7, K]
     phk_reduce_chunks       sums over the minibatch + the kernel object's flags -> buf [B + 1, 1 + 7K]
     (one all-reduce of buf over the ranks)
     phk_chain_rule          prior + J^T (d ll / d params) (+ the AFS term's value and gradient) -> logp [B], grad [B, D]
@@ -92,12 +93,13 @@ def particle_params(template: MCMCParams, x: torch.Tensor, double_precision: boo
     epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
     params = torch.empty((B, 1, 7, K), dtype=F64, device=dev)
     jac = torch.empty((B, 7 * K, D), dtype=F64, device=dev)
-    p32 = None if double_precision else torch.empty((B, 1, 7, K), dtype=torch.float32, device=dev)
-    _lib.check(_lib.load().phk_param_map_rounded(
+    _lib.check(_lib.load().phk_param_map(
         dev.index, K, P, epoch.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), float(template.theta), x.data_ptr(), B,
-        params.data_ptr(), jac.data_ptr(), p32.data_ptr() if p32 is not None else None,
-        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    return params, jac, (params if p32 is None else p32)
+        params.data_ptr(), jac.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    # (round 6: the float64 block goes to the kernel object as it is; a float32 object rounds it together with the folded
+    # factors it runs on, in float64 and once: HipEngine.run -> phk_prefold.  Round 5 rounded the rows here,
+    # phk_param_map_rounded, and the kernels folded the rounded rows.)
+    return params, jac, params
 
 
 def log_density_and_grad(template: MCMCParams, x: torch.Tensor, c, kern, local_inds, afs=None, afs_transform=None,

@@ -73,7 +73,9 @@ BARS = {  # name: bar                                  measured worst (round 4: 
     "smoke.f32": 8.1e-6,                           # 1.62e-6 of (own row + W = 0 row)
     "full_size.identity_pi.f32": 2e-3,             # 8.0e-4
     "full_size.identity_gamma.f32": 1.5e-3,        # 3.5e-4
-    "full_size.ll_grad_vs_nograd.f32": 1.5e-3,     # 3.1e-4 absolute, |ll| 2e3 .. 3e4
+    "full_size.ll_grad_vs_nograd.f32": 1e-2,       # round 6: 1.9e-3 .. 3.3e-3 absolute on rows of 60,500 / 100,500 sites, |ll| 2e3 .. 3e4 (1e-7
+                                                   # relative): the gradient call's ll carries the first-order correction for the float32 model's
+                                                   # rounding (phk_ll_first_order), the no-gradient call's cannot; round 5, neither did: 3.1e-4
     "full_size.ll_variants.f32": 2e-3,             # 7.7e-4 absolute
     "full_size.ll_plans.f32": 1e-3,                # 0 (the plans compared share their forward kernel); a variant change is ~3e-4
 }

@@ -371,7 +371,9 @@ def test_cfg3_one_rank_share_through_log_density():
     _oracle_sample(ll, g, pp.stack()[:, None], data, parts, chunks, W, False, "cfg3 share")
     # the ELPD-style evaluation (no gradient) gives the same HMM term from the no-gradient kernel
     with torch.no_grad():
-        np.testing.assert_allclose(kern.value(pp, inds).cpu(), ll.sum(1).cpu(), rtol=1e-7)
+        # (round 6: a gradient call's ll has the first-order effect of the float32 model's rounding taken back out, a
+        # no-gradient call's has not: 3-4e-7 relative apart on these rows)
+        np.testing.assert_allclose(kern.value(pp, inds).cpu(), ll.sum(1).cpu(), rtol=1e-6)
 
 
 def test_cfg2_full_batch_hybrid_plan(monkeypatch):
@@ -401,7 +403,9 @@ def test_cfg2_full_batch_hybrid_plan(monkeypatch):
     plan = eng.get_plan()
     # (segment sweep by the serial sweep's own 8-states-per-lane kernel since round 3: phk_api.hip, static_plan)
     assert plan.get("hybrid_first") == 32700 and plan["R_scan"] == 16 and plan["R_segment_sweep"] == 2, plan
-    assert torch.equal(ll_r, ll_d)  # (same forward kernel; the gradients come from different segment-sweep variants)
+    # (same forward kernel; the gradients come from different segment-sweep variants, and since round 6 a gradient call's ll
+    # carries a first-order correction formed from its gradient)
+    assert torch.allclose(ll_r, ll_d, rtol=1e-9, atol=0)
     monkeypatch.setenv("PHK_HYBRID", "2:1:32768:2:16")
     eng.set_deterministic(False)
     eng.set_autotune(False)

@@ -272,6 +272,46 @@ def test_out_of_range_chunk_index():
     assert not kern.check_rescaling(collective=True) and torch.isfinite(ok).all()
 
 
+@pytest.mark.parametrize("which,plan,name", [(1, (0, 2, 2, 0), "fwd_kernel"), (2, (0, 2, 2, 0), "bwd_kernel (serial sweep)"),
+                                             (2, (1, 2, 16, 16), "bwd_kernel (segment sweep)"), (4, (1, 2, 16, 16), "bscan_kernel"),
+                                             (1, (1, 2, 16, 16), "fwd_kernel")])
+def test_kernel_loops_are_bounded_by_a_host_budget(which, plan, name):
+    """Every kernel loop whose trip count derives from the launch arguments runs under an iteration budget the host computes
+    from the row length (KArgs::loop_budget: twice the block count).  A kernel that exhausts it raises a sticky flag, records
+    kernel / sequence / block and RETURNS instead of spinning; the next flag query fails with PHK_EOVERRUN (KernelOverrun)
+    naming them -- synchronously and through the all-reduce buffer of the multi-rank path.  Provoked through the test hook
+    ``phk_set_loop_budget_scale``: a quarter of the budget cannot cover a healthy row.  (one fuzz soak of
+    round 5 stalled unexplained; no argument can make a wave of these kernels loop without bound now.)"""
+    from phlash_amd import _lib
+    from phlash_amd.kernel import get_kernel
+    from phlash_amd.params import PSMCParams
+    from phlash_amd.synth import simulate_chunks
+
+    K, S, L = 16, 3, 4203
+    data = simulate_chunks(K, S, L, seed=9)
+    kern = get_kernel(K, data, False, overlap=100)
+    eng = kern._eng
+    eng.set_autotune(False)
+    eng.set_plan(plan[0], R=plan[1], T=8, R_forward=plan[2], R_scan=plan[3])
+    pp = PSMCParams.unstack(_params(K, 5, seed=10)[:, 0].cuda())
+    inds = torch.arange(S, device="cuda")
+    ll_ok, g_ok = kern.value_and_grad(pp, inds)
+    assert not kern.check_rescaling()
+    eng.set_loop_budget_scale(which, 1, 8)
+    kern.value_and_grad(pp, inds)  # returns: no hang, no fault
+    with pytest.raises(_lib.KernelOverrun, match=name.replace("(", r"\(").replace(")", r"\)")):
+        kern.check_rescaling()
+    assert not kern.check_rescaling()  # reported once, then clear
+    kern.value_and_grad(pp, inds)
+    dst = torch.zeros(2, dtype=torch.float64, device="cuda")
+    kern.take_flags_into(dst)
+    with pytest.raises(_lib.KernelOverrun):
+        kern.check_rescaling(collective=True)
+    eng.set_loop_budget_scale(7, 1, 1)  # back to the real budget: the same bits as before
+    ll, g = kern.value_and_grad(pp, inds)
+    assert not kern.check_rescaling() and torch.equal(ll, ll_ok) and torch.equal(g, g_ok)
+
+
 def test_flag_is_read_behind_the_launch_stream():
     """phk_underflow_risk on a non-default stream: PyTorch's pool streams are non-blocking, so a read on
     the null stream would not wait for the forward kernel.  The query now goes through the

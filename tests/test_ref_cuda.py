@@ -212,12 +212,22 @@ def test_f32_accuracy_on_nearly_empty_rows_next_to_the_reference_f32_kernels(L):
     ll_hg, _ = _engine(K, data, False).run(torch.tensor(P, device="cuda"), torch.tensor(inds, device="cuda"), 0, grad=True)
     ll_r32 = refcuda.call(K, False, data, inds, PB, grad=False)
     ll_r32g, _, _ = refcuda.call(K, False, data, inds, PB, grad=True)
-    ours = max(np.abs(ll_h - ll_o).max(), np.abs(ll_hg.cpu().numpy() - ll_o).max())
+    # round 6: ours against the oracle on the UNROUNDED float64 block (what a caller wants to know); the reference's float32
+    # kernels take float32 blocks and are held against the oracle on those, the comparison that favours them
+    ll_x = cport.batch(P, data, inds, 0, grad=False)
+    ours_ng = np.abs(ll_h - ll_x).max()                     # no-gradient call: the model rounded to float32, folded in float64
+    ours_g = np.abs(ll_hg.cpu().numpy() - ll_x).max()       # gradient call: ... and its first-order effect taken back out
+    rel_g = np.abs(ll_hg.cpu().numpy() / ll_x - 1).max()
+    model = np.abs(ll_o - ll_x).max()                       # what rounding the seven rows to float32 does to ll by itself
     ref = np.abs(ll_r32 - ll_o).max()
     ref_g = np.abs(ll_r32g - ll_o).max()
-    print(f"PARITY nearly empty rows, L = {L}, |ll| {np.abs(ll_o).min():.2f} .. {np.abs(ll_o).max():.2f}: absolute error of ll, ours {ours:.2e} "
-          f"({ours / L:.1e} per site); reference float32 kernels: loglik {ref:.2e}, loglik_grad {ref_g:.2e}")
-    assert ours <= 3e-8 * L, (ours, L)
+    print(f"PARITY nearly empty rows, L = {L}, |ll| {np.abs(ll_x).min():.2f} .. {np.abs(ll_x).max():.2f}: absolute error of ll vs the oracle on "
+          f"unrounded parameters: gradient call {ours_g:.2e} ({ours_g / L:.1e} per site, {rel_g:.1e} relative), no-gradient call "
+          f"{ours_ng:.2e} ({ours_ng / L:.1e} per site); the rounding of the rows alone {model:.2e}; reference float32 kernels vs the oracle "
+          f"on ROUNDED parameters: loglik {ref:.2e}, loglik_grad {ref_g:.2e}")
+    # (measured on the MI355X: 9.2e-10 / 1.2e-9 / 2.1e-9 per site at 4,107 / 20,000 / 60,500 sites; the shortest row 4.4e-7 relative)
+    assert ours_g <= 6e-9 * L and (rel_g <= 1e-5 or L > 4107), (ours_g, rel_g, L)
+    assert ours_ng <= 3e-8 * L, (ours_ng, L)
 
 
 @pytest.mark.gpu
