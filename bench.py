@@ -633,10 +633,18 @@ def main():
         achieved = alg_bytes / bwd_avg_s / 1e9
         traffic = None
         issue_floor = None  # VALU issue floor of the step from the static counter file (scripts/issue_floor.py)
+        traffic_build_matches = None  # were the static counters taken on the library this process has loaded?
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        try:
+            from build_id import lib_sha256
+            loaded_sha = lib_sha256()
+        except Exception:
+            loaded_sha = None
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
+                traffic_build_matches = bool(loaded_sha) and pj.get("lib_sha256") == loaded_sha
                 if pj.get("workload") == f"K{K}_B{B}_S{S}_L{L}_W{W}_{'f64' if a.double else 'f32'}" and a.het_rate is None and a.theta == 1e-2:
                     traffic = pj.get("bwd_kernel_hbm_bytes_per_launch")
                     v = pj.get("valu")
@@ -693,6 +701,10 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # the counters are a static file (profiles/pmc_summary.json); this says whether they were taken on the very
+                # library this process has loaded (sha256 of libphlash_hip.so recorded by scripts/profile.sh)
+                "traffic_build_matches": traffic_build_matches,
+                "loaded_lib_sha256": loaded_sha,
                 "traffic_source": ("profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                    "command on an earlier run (static file, not collected by this process)"
                                    if traffic is not None else None),
@@ -724,6 +736,7 @@ def main():
                 if tab:
                     row = tab.get(f"N={world}") or {}
                     out["scaling_expectation"] = {
+                        "build_matches": bool(loaded_sha) and (ex.get("build") or {}).get("lib_sha256") == loaded_sha,
                         "n1_value": tab.get("N=1", {}).get("value"),
                         "per_rank_ms_per_step_measured_alone": row.get("ms_per_step"),
                         "expected_value_at_this_n": row.get("value"),

@@ -283,6 +283,9 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #ifndef PHK_FOLD
 #define PHK_FOLD 1  // A/B: 0 = no float32 kernel folds its hom emission into the factors
 #endif
+#ifndef PHK_FOLD_F64
+#define PHK_FOLD_F64 1  // 1 = the float64 kernels run on the folded model too (round 6 experiment)
+#endif
 #ifndef PHK_SWEEP_FOLD
 #define PHK_SWEEP_FOLD PHK_FOLD  // A/B: 0 = the sweeps' hot body keeps its per-site emission rows (the model is folded all the same)
 #endif
@@ -448,7 +451,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // that is the same at every site and adds up along the row (60,000 sites: sum(alpha .* beta) drifts 6e-4 from 1
     // and takes every gradient row with it).  float64 kernels keep their emissions in the table.
     __device__ __forceinline__ bool try_fold(const real* pf = nullptr) {
-        if constexpr (sizeof(real) == 4 && PHK_FOLD != 0) {
+        if constexpr ((sizeof(real) == 4 || PHK_FOLD_F64 != 0) && PHK_FOLD != 0) {
             const bool ok = emissions_foldable();
             if (ok) fold_emissions(pf);
             return ok;
@@ -1057,7 +1060,7 @@ constexpr bool bwd_straight_line() { return T * (K / R) * (int)sizeof(real) <= 1
 // operators in the prologue has long live ranges) -- one wave per SIMD, so that the forward kernel and
 // the beta scan of the segmented plan, 625 waves each at the reference's production shape, could not
 // share the 1,024 SIMDs and ran one after the other.  Their loops need fewer than 100 registers.
-// Measured at 500 x 5 x 100,000 (interleaved A/B, profiles/r02_ab_experiments.txt): 1 wave per SIMD 11.8-12.4
+// Measured at 500 x 5 x 100,000 (interleaved A/B, round 2): 1 wave per SIMD 11.8-12.4
 // ms per step, 2 waves 9.3, 4 waves 9.3-9.4; one 100,000-site sequence: 5.56 / 5.33 / 5.60 ms.
 #ifndef PHK_DENSE_WAVES
 #define PHK_DENSE_WAVES 2
@@ -1227,7 +1230,7 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void f
     // blocks at 1 % hets -- runs without a single emission row (no LDS gather, no multiply: a timing-only build of the
     // one-lane forward kernel without them ran cfg2's forward phase in 8.1 instead of 10.8 ms); any other block takes
     // the straight-line path with per-lane codes as ever, its rows now the ratios emis1 / emis0, 1 / emis0 and 1.
-    constexpr bool FOLD = !DENSE && sizeof(real) == 4 && PHK_FWD_FOLD != 0;
+    constexpr bool FOLD = !DENSE && (sizeof(real) == 4 || PHK_FOLD_F64 != 0) && PHK_FWD_FOLD != 0;
     constexpr bool FREG = FOLD && PHK_FWD_HET_REGS != 0;
     V rhet[NP], rmis[NP];  // FREG: a folded lane's ratio rows emis1 / emis0 and 1 / emis0 (see fold_block)
     if constexpr (FREG) {
@@ -1809,7 +1812,7 @@ constexpr int bwd_waves_per_simd() {
 // touched at het / missing sites only -- live in LDS behind the emission table, [3][EROW] reals indexed by the site's
 // code like the table itself.
 template <typename real, int K, int R, int T, int NRM>
-constexpr bool sweep_folds() { return PHK_SWEEP_FOLD != 0 && sizeof(real) == 4 && PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * (K / R) * (int)sizeof(real) <= 256; }
+constexpr bool sweep_folds() { return PHK_SWEEP_FOLD != 0 && (sizeof(real) == 4 || PHK_FOLD_F64 != 0) && PHK_SWEEP_V2 != 0 && NRM > 1 && T == 8 && T * (K / R) * (int)sizeof(real) <= 256; }
 #ifndef PHK_PARK_HREG
 #define PHK_PARK_HREG 2  // ... of the folded bodies with PHK_HET_REGS: 68 floats of LDS per thread = 69,632 B per 256-thread workgroup, two
                          // workgroups per CU (the launcher raises the kernel's dynamic-LDS limit: launch.hip, bwd_rtn).  Every parked

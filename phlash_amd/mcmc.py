@@ -28,6 +28,7 @@ Differences from the reference, all deliberate:
 
 from __future__ import annotations
 
+import operator
 import os
 import warnings
 
@@ -101,11 +102,23 @@ def _join_process_group(device=None) -> int:
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible: phlash_amd.fit needs an MI355X (there is no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if device is not None:  # an ordinal, "cuda:1" or a torch.device
-        device = device if isinstance(device, int) else torch.device(device).index
-        if device is None or not 0 <= device < torch.cuda.device_count():
-            raise ValueError(f"fit(device=...): no such HIP device among the {torch.cuda.device_count()} visible")
+    if device is not None:  # an ordinal (any integer type), "cuda", "cuda:1" or a torch.device
+        if isinstance(device, bool):
+            raise TypeError("fit(device=...): an ordinal, a device string or a torch.device, not a bool")
+        try:
+            device = operator.index(device)  # int, numpy integers, ...
+        except TypeError:
+            td = torch.device(device)
+            if td.type != "cuda":
+                raise ValueError(f"fit(device={device!r}): phlash_amd runs on HIP devices only (there is no CPU fallback)")
+            device = torch.cuda.current_device() if td.index is None else td.index  # "cuda" = the current device
+        if not 0 <= device < torch.cuda.device_count():
+            raise ValueError(f"fit(device=...): no HIP device {device} among the {torch.cuda.device_count()} visible")
         torch.cuda.set_device(device)
+        if world > 1 and "LOCAL_RANK" in os.environ and torch.cuda.device_count() > 1 and device != int(os.environ["LOCAL_RANK"]):
+            # (every rank of a torchrun launch that passes the same device= lands on ONE GPU: RCCL then fails or hangs)
+            warnings.warn(f"fit(device={device}) in rank LOCAL_RANK={os.environ['LOCAL_RANK']} of a {world}-rank job: if every rank "
+                          "passes the same device they all share one GPU (RCCL needs one GPU per rank)")
     if dist.is_available() and dist.is_initialized():
         # The caller set the group up.  If it also chose a device (explicit device= option, one visible GPU
         # per rank, or it already moved off device 0) that choice stands.  A caller who only ran

@@ -34,6 +34,7 @@ from .util import get_pattern
 F64 = torch.float64
 
 _afs_consts: dict = {}
+AFS_HIP_MAX = 128  # phk_afs_term: sample size n and transform rows m it accepts (AF_MAXN)
 
 
 def _afs_constants(afs, afs_transform, dev: torch.device):
@@ -67,6 +68,17 @@ def afs_term_and_grad(template: MCMCParams, x: torch.Tensor, afs, afs_transform=
     K, P = pat.M, len(pat)
     assert D == P + 3
     n, m, tw, w1, y = _afs_constants(afs, afs_transform, dev)
+    if n > AFS_HIP_MAX or m > AFS_HIP_MAX:
+        # the HIP kernel keeps the n - 1 branch-length duals of a particle in registers (AF_MAXN = 128, csrc/step_args.h);
+        # larger spectra -- more than 64 diploid samples, which the reference handles (model.py:58-68 has no limit) -- take the
+        # autograd definition: a few dozen small torch launches instead of one, the same numbers
+        from .model import afs_term
+
+        with torch.enable_grad():
+            xs = x.detach().requires_grad_(True)
+            val = afs_term(template.from_flat(xs).to_dm(), afs, afs_transform)
+            (grad,) = torch.autograd.grad(val.sum(), xs)
+        return val.detach(), grad
     epoch = np.array([e for e, w in enumerate(pat.widths) for _ in range(w)], dtype=np.int32)
     val = torch.empty(B, dtype=F64, device=dev)
     grad = torch.empty((B, D), dtype=F64, device=dev)

@@ -31,7 +31,9 @@ if [ "$MODE" = full ]; then
   unset PHK_DETERMINISTIC
 fi
 cd "$REPO"
+python3 scripts/build_id.py > "$OUT/build.json"  # which library these counters belong to (bench.py: roofline.traffic_build_matches)
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+echo "build: $(cat "$OUT/build.json")" >> "$OUT/summary.txt"
 # keep only the small files for the merge back (<= 64 MiB)
 find "$OUT" -name "*.db" -delete
 find "$OUT" -size +8M -delete

@@ -116,6 +116,10 @@ def main():
         exp["prod"] = {f"N={n}": {"ms_per_step": pm[f"N={n}"]["ms_per_step"], "value": work / (pm[f"N={n}"]["ms_per_step"] * 1e-3),
                                   "speedup": round(t1 / pm[f"N={n}"]["ms_per_step"], 3)} for n in (1, 2, 4, 8) if "ms_per_step" in pm.get(f"N={n}", {})}
     res["bench_expectation"] = exp
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from build_id import build_id
+
+    res["build"] = build_id()  # (bench.py: scaling_expectation.build_matches)
     print(json.dumps(res, indent=1))
 
 

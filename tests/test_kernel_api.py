@@ -328,7 +328,7 @@ def test_log_prior_kernel_matches_the_torch_definition(P, alpha, beta):
 
 
 @pytest.mark.parametrize("dbl", [True, False])
-@pytest.mark.parametrize("with_afs", [False, True])
+@pytest.mark.parametrize("with_afs", [False, True, 140])
 def test_fused_step_matches_the_autograd_definition(rng, dbl, with_afs):
     """``phlash_amd.step.log_density_and_grad`` (parameter map -> kernels -> phk_reduce_chunks -> phk_chain_rule, no
     autograd) against ``mcmc._log_density_population`` differentiated by autograd (the definition): value and
@@ -347,7 +347,9 @@ def test_fused_step_matches_the_autograd_definition(rng, dbl, with_afs):
     kern = get_kernel(16, chunks, dbl, overlap=W)
     dev = kern.device
     X = (init.flat[None] + 0.4 * torch.tensor(rng.normal(size=(13, 18)))).to(dev)
-    afs = 1e3 / np.arange(1, 12) if with_afs else np.ones(1)
+    # (with_afs = 140: a spectrum of 140 haploids, beyond the 128 the HIP AFS kernel holds in registers -- the fused step
+    # then takes the term from the autograd definition instead of refusing; the reference has no limit, model.py:58-68)
+    afs = (1e3 / np.arange(1, 140 if with_afs == 140 else 12)) if with_afs else np.ones(1)
     c = (1.0, 9.0 / 4, 1.0)
     ct = torch.tensor(c, dtype=F64, device=dev)
     assert step.fusable(template, kern)
