@@ -2657,7 +2657,8 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             g0[h] = *(const V*)(gtab + g0code * L::EROW + 2 * h);
-            g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
+            if constexpr (HREG) g1[h] = g1[h] + *(const V*)(gtab + 1 * L::EROW + 2 * h);  // (registers: hot body; LDS row: general body)
+            else g1[h] = *(const V*)(gtab + 1 * L::EROW + 2 * h);
         }
     }
     // d ll / d theta (or theta * that), rows b,d,u,v,emis0,emis1,pi
