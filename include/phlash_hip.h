@@ -234,6 +234,12 @@ int phk_underflow_risk(phk_handle* h, int* flag);
  * kernel, bit 1 backward kernel, bit 2 beta scan.  A scale below ~1/2 makes a healthy evaluation overrun, which is how
  * tests/test_plans_and_modes.py exercises the PHK_EOVERRUN path. */
 int phk_set_loop_budget_scale(phk_handle* h, int kernels, int num, int den);
+/* Developer builds (-DPHK_ASM_RUN=1) only: the K = 16 float32 sweeps with two lanes per sequence run their hot blocks through a
+ * hand-written instruction sequence (csrc/sweep_run_k16r2.inc, generated by scripts/gen_sweep_asm.py: the C++ body's arithmetic,
+ * operation for operation, an all-hom block without its per-site tests) when on = 1.  It returns the same bits as the C++ body
+ * (tests/test_hip_parity.py::test_asm_block_run_equals_the_cxx_body) and measured 1-2 % slower (profiles/r06_ab_experiments.txt
+ * item 8), so the shipped library is built without it and answers on = 1 with PHK_EUNSUPPORTED. */
+int phk_set_asm_run(phk_handle* h, int on);
 /* The same flag word handed over WITHOUT a host synchronisation: a one-thread kernel on `stream`
  * writes dst[0] = 1.0 if the underflow-risk bit is set (else 0.0), dst[1] = 1.0 if a chunk index was
  * outside [0, N) (else 0.0) -- `dst` is a device array of two doubles -- and clears the word.  The

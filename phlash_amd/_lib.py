@@ -46,6 +46,7 @@ SIGNATURES = {
     "phk_take_flags_async": (_i, [_vp, _vp, _vp]),
     "phk_set_deterministic": (_i, [_vp, _i]),
     "phk_set_loop_budget_scale": (_i, [_vp, _i, _i, _i]),
+    "phk_set_asm_run": (_i, [_vp, _i]),
     "phk_set_autotune": (_i, [_vp, _i]),
     "phk_set_backward_mode": (_i, [_vp, _i]),
     "phk_set_plan": (_i, [_vp, _i, _i, _i, _i, _i]),

@@ -152,6 +152,7 @@ struct phk_handle {
     hipStream_t side = nullptr;  // second stream of the segmented plan
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
+    int asm_run = 0;  // phk_set_asm_run (developer builds with -DPHK_ASM_RUN=1)
     int budget_num[3] = {1, 1, 1}, budget_den[3] = {1, 1, 1};  // phk_set_loop_budget_scale (tests): forward kernel, backward kernel, beta scan
     int poison = 0;  // diagnostic: fill the scratch buffers with this byte before every launch sequence (PHK_POISON=255: NaN patterns)
     std::vector<hipEvent_t> ev;  // triples (start, mid, end) per launch since the last timing query
@@ -766,6 +767,9 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     if (const char* env = std::getenv("PHK_AUTOTUNE")) h->autotune = std::atoi(env) != 0;
     if (const char* env = std::getenv("PHK_DETERMINISTIC")) h->deterministic = std::atoi(env) != 0;
     if (const char* env = std::getenv("PHK_POISON")) h->poison = std::atoi(env);
+#if PHK_ASM_RUN
+    if (const char* env = std::getenv("PHK_ASM_RUN")) h->asm_run = std::atoi(env) != 0;
+#endif
     if (h->risk.ensure(4 * sizeof(int)) != PHK_OK || hipMemset(h->risk.p, 0, 4 * sizeof(int)) != hipSuccess) {  // flag word + (kernel, sequence, block) of an overrun
         delete h;
         return fail(PHK_ENOMEM, "could not allocate the underflow flag");
@@ -966,6 +970,15 @@ int phk_take_flags_async(phk_handle* h, double* dst, void* stream) {
     HIP_TRY(hipSetDevice(h->device));
     hipLaunchKernelGGL(phk::take_flags_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)h->risk.p, dst);
     HIP_TRY(hipGetLastError());
+    return PHK_OK;
+}
+
+int phk_set_asm_run(phk_handle* h, int on) {
+    if (!h) return fail(PHK_EINVAL, "handle is NULL");
+#if !PHK_ASM_RUN
+    if (on) return fail(PHK_EUNSUPPORTED, "this library was built without the hand-written block-run sequence (-DPHK_ASM_RUN=1: developer builds)");
+#endif
+    h->asm_run = on ? 1 : 0;
     return PHK_OK;
 }
 
@@ -1316,6 +1329,7 @@ static int loglik_impl(phk_handle* h, const void* params, int64_t pstride_b, int
         a.ops_f = a.ops_b = nullptr;  // build_dense_ops sets them where the plan runs a one-state-per-lane kernel
         // the pre-folded blocks are laid out like the parameter blocks, five rows instead of seven
         for (int i = 0; i < 4; ++i) a.loop_budget[i] = INT32_MAX;  // enqueue() sets the plan's values
+        a.asm_run = h->asm_run;
         a.pfstride_b = pstride_b / 7 * 5;
         a.pfstride_s = pstride_s / 7 * 5;
         a.prefold = prefold ? prefold + (b0 * a.pfstride_b + s0 * a.pfstride_s) : nullptr;

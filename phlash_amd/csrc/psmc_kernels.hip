@@ -283,6 +283,13 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #ifndef PHK_FOLD
 #define PHK_FOLD 1  // A/B: 0 = no float32 kernel folds its hom emission into the factors
 #endif
+#ifndef PHK_ASM_RUN
+#define PHK_ASM_RUN 0  // 1 (developer builds: scripts/ab_build.sh <tag> f32 16 -DPHK_ASM_RUN=1): the K = 16, R = 2 float32 sweeps run their
+                       // hot blocks through the generated instruction sequence sweep_run_k16r2.inc (scripts/gen_sweep_asm.py) when the
+                       // handle asks for it (phk_set_asm_run).  Bit-identical to the C++ body and 1-2 % SLOWER than it
+                       // (profiles/r06_ab_experiments.txt item 8), hence not in the shipped library
+#endif
+constexpr bool SEG_DISABLED_ASM = false;
 #ifndef PHK_FOLD_F64
 #define PHK_FOLD_F64 1  // 1 = the float64 kernels run on the folded model too (round 6 experiment)
 #endif
@@ -975,6 +982,7 @@ struct KArgs {
     // wave spin until the watchdog takes the GPU away.  [0] forward kernel (outer iterations: one per 64-site piece or per
     // block of a ragged piece), [1] serial sweep (blocks), [2] beta scan (pieces / words), [3] one unit of the segment sweep (blocks).
     int32_t loop_budget[4];
+    int32_t asm_run;  // 1: the K = 16, R = 2 float32 sweeps run their hot blocks through the hand-written sequence (0: the C++ body; tests)
 };
 
 // this sequence's pre-folded block (lane slice added by the caller), or null
@@ -2193,6 +2201,36 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
             if (blk - stop + 1 > budget) stop = blk - budget + 1;  // (the budget bounds the run: no test inside the block loop)
             budget -= blk - stop + 1;
             const int first = blk;
+#if PHK_ASM_RUN
+            // K = 16, R = 2, float32: the whole run of hot blocks as ONE hand-written instruction sequence (scripts/gen_sweep_asm.py):
+            // an all-hom block runs without the sixteen per-site tests of the body below, a mixed block with them, under one
+            // register plan -- what the compiler cannot do at the join of two C++ bodies.  Same arithmetic, operation for
+            // operation; waves that hold more than two observation rows keep the C++ loop.
+            if constexpr (HREG && !HREG2 && sizeof(real) == 4 && K == 16 && R == 2 && !SEG_DISABLED_ASM) {
+                if (A.asm_run != 0 && two_rows && blk >= stop) {
+                    // (the statement's scalar operands must be SGPRs to the compiler's divergence analysis, which cannot see that
+                    // `stop` -- it depends on whether this unit owns a partial-sum slot -- is the same in every lane)
+                    auto uni64 = [](int64_t x) {
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)x);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+                        return ((uint64_t)hi << 32) | lo;
+                    };
+                    uint64_t asm_ckq = (uint64_t)ckq, asm_ebq = (uint64_t)ebq;
+                    const uint64_t asm_words = (uint64_t)words;
+                    const uint32_t asm_lds = (uint32_t)(uintptr_t)etab;
+                    const uint64_t asm_ckstep = uni64(-(ck_step * (int64_t)sizeof(real)));
+                    const uint64_t asm_ebstep = uni64(-(nseq * (int64_t)sizeof(int16_t)));
+                    const uint64_t asm_ckpiece = uni64(nseq * 4 * (int64_t)sizeof(real));
+                    int asm_blk = __builtin_amdgcn_readfirstlane(blk), asm_widx = __builtin_amdgcn_readfirstlane(widx);
+                    const int asm_stop = __builtin_amdgcn_readfirstlane(stop), asm_blklo = __builtin_amdgcn_readfirstlane(blk_lo);
+#include "sweep_run_k16r2.inc"
+                    blk = asm_blk;
+                    widx = asm_widx;
+                    ckq = (const real*)asm_ckq;
+                    ebq = (const int16_t*)asm_ebq;
+                }
+            }
+#endif
             for (; blk >= stop; --blk) {
                 int e_fwd;
                 uint32_t codes;

@@ -107,6 +107,10 @@ class HipEngine:
         kernel (bit 1), the beta scan (bit 2)."""
         _lib.check(_lib.load().phk_set_loop_budget_scale(self._h, int(kernels), int(num), int(den)))
 
+    def set_asm_run(self, on: bool):
+        """The hand-written block-run sequence of the K = 16 float32 sweeps on / off (``phk_set_asm_run``; off = the C++ body)."""
+        _lib.check(_lib.load().phk_set_asm_run(self._h, int(bool(on))))
+
     def set_deterministic(self, on: bool):
         _lib.check(_lib.load().phk_set_deterministic(self._h, int(bool(on))))
 

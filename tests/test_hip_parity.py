@@ -849,3 +849,44 @@ def test_last_sequence_of_a_partly_filled_workgroup(S, T):
             np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
             worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
             assert worst < 1.0, (rep, form, worst)
+
+
+@pytest.mark.parametrize("het,B,S,L,W,plan", [
+    (0.01, 100, 3, 4203, 101, "serial"), (0.10, 100, 3, 4203, 0, "serial"), (0.30, 37, 4, 2600, 515, "serial"),
+    (0.05, 100, 3, 4203, 101, "segmented"), (0.10, 64, 2, 8200, 500, "segmented"), (0.02, 100, 6, 4203, 40, "hybrid"),
+    (0.0, 33, 2, 1030, 0, "serial"),
+])
+def test_asm_block_run_equals_the_cxx_body(het, B, S, L, W, plan, monkeypatch):
+    """The K = 16 float32 sweeps (two lanes per sequence) run their hot blocks through a hand-written instruction sequence
+    (csrc/sweep_run_k16r2.inc, scripts/gen_sweep_asm.py): an all-hom block without the per-site tests, a mixed block with them,
+    one register plan.  It performs the C++ body's arithmetic operation for operation, so switching it off
+    (``phk_set_asm_run``) must give the SAME BITS -- log-likelihoods and every gradient row -- on rows with hets, missing runs,
+    a warm-up boundary, in the serial, the segmented and the hybrid plan; and both agree with the oracle."""
+    rng = np.random.default_rng(int(1000 * het) + B + L)
+    data = (rng.uniform(size=(S, L)) < het).astype(np.int8)
+    data.flat[rng.integers(0, data.size, data.size // 100)] = -1
+    data[0, L // 3:L // 3 + 40] = -1
+    data[:, 0] = np.maximum(data[:, 0], 0)
+    P = _params(16, B, 1, seed=B + S)
+    inds = np.arange(S)
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    eng.set_rescale_interval(4)
+    if plan == "serial":
+        eng.set_plan(0, R=2, T=8, R_forward=1, R_scan=0)
+    elif plan == "segmented":
+        eng.set_plan(1, R=2, T=8, R_forward=16, R_scan=16)
+    else:
+        monkeypatch.setenv("PHK_HYBRID", f"2:1:{B * (S // 2)}:2:16")
+    try:
+        eng.set_asm_run(True)
+    except NotImplementedError:
+        pytest.skip("the library was built without -DPHK_ASM_RUN=1 (the shipped build: the sequence is 1-2 % slower than the C++ body)")
+    ll_a, g_a = _run(eng, P, inds, W)
+    eng.set_asm_run(False)
+    ll_c, g_c = _run(eng, P, inds, W)
+    assert np.array_equal(ll_a, ll_c)
+    assert np.array_equal(g_a, g_c), float(np.abs(g_a - g_c).max())
+    ll_ref, g_ref = cport.batch(P, data, inds, W)
+    np.testing.assert_allclose(ll_a, ll_ref, rtol=1e-5, atol=1e-5)
+    assert _grad_within_fuzz_bound(g_a, g_ref, P, P, data, inds, W, False) < 1.0
