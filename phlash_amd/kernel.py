@@ -247,6 +247,12 @@ class PSMCKernel:
         self._eng.take_flags_async(dst)
         self._flags = dst
 
+    def flags_consumed(self):
+        """The flags a sharded evaluation moved off the device word (``take_flags_into``) have been read and judged by the
+        caller itself (``fit``'s speculative held-out score reads them out of its own all-reduced buffer): forget the buffer,
+        so that the next ``check_rescaling`` does not read it a second time."""
+        self._flags = None
+
     def check_rescaling(self, collective: bool = False, also: torch.Tensor | None = None) -> bool:
         """True (after switching to per-site rescaling) if an evaluation since the last check hit
         parameters too extreme for the current rescale interval; the caller should redo that step.

@@ -76,6 +76,9 @@ class _NoRows:
     def take_flags_into(self, dst):
         self._flags = dst  # nothing of its own to hand over: dst stays zero on this rank
 
+    def flags_consumed(self):
+        self._flags = None
+
     def check_rescaling(self, collective: bool = False, also=None) -> bool:
         self.also_value = None
         if self._flags is None:
@@ -464,7 +467,7 @@ def fit(data: list, test_data=None, **options) -> list[DemographicModel]:
         torch.cuda.current_stream(dev).wait_event(done)  # (the buffer is written on the side stream)
         parallel.all_reduce_sum_(tot)
         e, under, bad = (float(v) for v in tot.cpu())  # synchronises; the same three numbers on every rank
-        k_._flags = None
+        k_.flags_consumed()
         _lib.check_failure_slot(bad, "held-out rows")
         if under > 0:  # extreme particles: once more with per-site rescaling, at once and in line
             k_.switch_to_per_site_rescaling()
