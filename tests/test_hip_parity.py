@@ -524,8 +524,10 @@ def test_random_shapes_against_the_oracle(seed):
     # (... and per site like every float32 ll bar: dense operator steps and structured steps round the folded model
     # differently but each the same way at every site -- seed 12579 of the round-5 soak: 2,600 all-hom sites, |ll| = 1.1,
     # the two calls 2.3e-5 = 9e-9 per site apart, both inside their oracle bar)
-    # (round 6: the no-gradient call has no gradient to correct its ll with and keeps the per-site figure: 3e-8 per site)
-    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else max(2e-5, 3e-8 * L))
+    # (round 6: the gradient call's ll is corrected to first order for the rounding of the model, the no-gradient call has no
+    # gradient to correct with and keeps the per-site figure of a float32 model -- typically 2e-8 per site, up to 6e-8 on 31 of
+    # 6,000 random shapes (profiles/r06_fuzz_soak.txt): the bar round 5 held BOTH calls to against the oracle, 1e-7 per site)
+    np.testing.assert_allclose(ll_only, ll, rtol=1e-12 if dbl else 1e-6, atol=1e-9 if dbl else max(2e-5, 1e-7 * L))
 
 
 def _runs_data(rng, n, L, het=0.02, miss_runs=3):
@@ -616,9 +618,9 @@ def test_dense_kernels_random_shapes(seed):
         assert slab[0] * slab[1] < B * S, slab
     ll_ref, g_ref = cport.batch(Pin, data, inds, W)
     # (gradient call: 1e-5 relative, flat 1e-5 absolute; the no-gradient call keeps the model's rounding: never less than
-    # 3e-8 per site)
+    # 1e-7 per site)
     np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=max(1e-5, 3e-8 * L))
+    np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=max(1e-5, 1e-7 * L))
     worst = _grad_within_fuzz_bound(g, g_ref, P, Pin, data, inds, W, False)
     print(f"dense fuzz seed={seed} B={B} S={S} L={L} W={W} het={het} T={T} form={form} hybrid={hybrid} slab={slab}: "
           f"err/bound {worst:.2f}")
