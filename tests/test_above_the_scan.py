@@ -447,3 +447,52 @@ def test_phk_afs_term_against_oracle_and_autograd(K, n, transformed):
     for b in range(X.shape[0]):
         d = o.particle_to_dm(X[b], pat, 1e-2)
         np.testing.assert_allclose(float(val[b]), oafs.afs_term(d.t, d.c, afs, T), rtol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_phk_prefold_against_numpy(K):
+    """``phk_prefold`` through ctypes: the float32 rounding of the seven rows, the folded factors fl(e0 b), fl(e0 d), fl(e0 v),
+    fl(e1 / e0), fl(1 / e0) formed in float64 and rounded ONCE, and the first-order coefficients ``crel`` -- each against its
+    definition written out in numpy (bit for bit: IEEE products and quotients in float64, one conversion to float32)."""
+    L, lib = _lib()
+    pat, P, X = _population(K, 17, seed=100 + K)
+    Pn = np.stack([o.from_dm(o.particle_to_dm(xb, pat, 1e-2)).stack() for xb in X])  # [B, 7, K] float64
+    Pn[3, 4, 2] = 0.0  # one block that cannot fold (an emis0 of 0 is below the kernels' 2^-64): crel falls back to the rows' residuals
+    B = Pn.shape[0]
+    p64 = torch.tensor(Pn, device="cuda")
+    p32 = torch.empty((B, 7, K), dtype=torch.float32, device="cuda")
+    pf = torch.empty((B, 5, K), dtype=torch.float32, device="cuda")
+    crel = torch.empty((B, 7, K), dtype=torch.float64, device="cuda")
+    L.check(lib.phk_prefold(0, K, p64.data_ptr(), B, p32.data_ptr(), pf.data_ptr(), crel.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    b, d, u, v, e0, e1, pi = (Pn[:, r] for r in range(7))
+    assert np.array_equal(p32.cpu().numpy(), Pn.astype(np.float32))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rh = np.where(e0 > 0, e1 / e0, 1.0)
+        rm = np.where(e0 > 0, 1.0 / e0, 1.0)
+    want_pf = np.stack([e0 * b, e0 * d, e0 * v, rh, rm], 1)
+    assert np.array_equal(pf.cpu().numpy(), want_pf.astype(np.float32))
+
+    def res(x):  # relative residual of one rounding to float32
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(x != 0, (x - x.astype(np.float32).astype(np.float64)) / x, 0.0)
+
+    folds = (e0.astype(np.float32) > np.float32(2.0 ** -64)).all(1)[:, None]
+    em = res(rm)
+    want_c = np.where(folds[:, None], np.stack([res(e0 * b) + em, res(e0 * d) + em, res(u), res(e0 * v) + em, -em, res(rh) - em, res(pi)], 1),
+                      np.stack([res(Pn[:, r]) for r in range(7)], 1))
+    assert not folds[3] and folds.sum() == B - 1
+    np.testing.assert_allclose(crel.cpu().numpy(), want_c, rtol=1e-12, atol=1e-22)
+    # ... and the correction kernel: ll += sum_j theta_j g_j crel_j (g = d ll / d theta), or sum_j g_j crel_j for the dlog form
+    S = 3
+    rng = np.random.default_rng(K)
+    g = rng.normal(size=(B, S, 7, K)).astype(np.float32)
+    ll0 = rng.normal(size=(B, S))
+    for dlog in (0, 1):
+        ll = torch.tensor(ll0, device="cuda")
+        gt = torch.tensor(g, device="cuda")
+        L.check(lib.phk_ll_first_order(0, K, ll.data_ptr(), gt.data_ptr(), dlog, p64.data_ptr(), crel.data_ptr(), 7 * K, 0, B, S, _stream()))
+        torch.cuda.synchronize()
+        w = want_c if dlog else want_c * Pn
+        np.testing.assert_allclose(ll.cpu().numpy(), ll0 + np.einsum("bsrk,brk->bs", g.astype(np.float64), w), rtol=1e-12, atol=1e-18)

@@ -274,3 +274,19 @@ def test_chunk_layout_equals_reference_executed():
         got = chunk_het_matrix(chunk_input(n, L, seed), ov, cs)
         assert got.dtype == np.int8
         np.testing.assert_array_equal(got, G[f"chunk_{i}"])
+
+
+def test_failure_slot_of_the_flag_hand_over_decodes_index_errors_and_overruns():
+    """The second slot of the stream-ordered flag hand-over (``take_flags_kernel`` / the flag row of ``phk_reduce_chunks``,
+    possibly summed over ranks) counts chunk indices out of range by 1 and kernels that ran out of their loop budget by 4096:
+    ``_lib.check_failure_slot`` raises AssertionError (gpu.py:197-199) for the first, KernelOverrun for the second."""
+    from phlash_amd import _lib
+
+    _lib.check_failure_slot(0.0, "N=5")
+    with pytest.raises(AssertionError, match="outside"):
+        _lib.check_failure_slot(3.0, "N=5")  # three ranks saw a bad index
+    with pytest.raises(_lib.KernelOverrun):
+        _lib.check_failure_slot(4096.0, "N=5")
+    with pytest.raises(_lib.KernelOverrun):
+        _lib.check_failure_slot(2 * 4096.0 + 1.0, "on another rank")
+    assert issubclass(_lib.KernelOverrun, _lib.HipError)
