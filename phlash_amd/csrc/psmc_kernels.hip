@@ -289,9 +289,8 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
                        // handle asks for it (phk_set_asm_run).  Bit-identical to the C++ body and 1-2 % SLOWER than it
                        // (profiles/r06_ab_experiments.txt item 8), hence not in the shipped library
 #endif
-constexpr bool SEG_DISABLED_ASM = false;
 #ifndef PHK_FOLD_F64
-#define PHK_FOLD_F64 1  // 1 = the float64 kernels run on the folded model too (round 6 experiment)
+#define PHK_FOLD_F64 1  // A/B: 0 = the float64 kernels keep their emissions in the table (rounds 1-5); 1: folded like the float32 ones (round 6: cfg2 76 -> 67 ms)
 #endif
 #ifndef PHK_SWEEP_FOLD
 #define PHK_SWEEP_FOLD PHK_FOLD  // A/B: 0 = the sweeps' hot body keeps its per-site emission rows (the model is folded all the same)
@@ -2206,7 +2205,7 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
             // an all-hom block runs without the sixteen per-site tests of the body below, a mixed block with them, under one
             // register plan -- what the compiler cannot do at the join of two C++ bodies.  Same arithmetic, operation for
             // operation; waves that hold more than two observation rows keep the C++ loop.
-            if constexpr (HREG && !HREG2 && sizeof(real) == 4 && K == 16 && R == 2 && !SEG_DISABLED_ASM) {
+            if constexpr (HREG && !HREG2 && sizeof(real) == 4 && K == 16 && R == 2) {
                 if (A.asm_run != 0 && two_rows && blk >= stop) {
                     // (the statement's scalar operands must be SGPRs to the compiler's divergence analysis, which cannot see that
                     // `stop` -- it depends on whether this unit owns a partial-sum slot -- is the same in every lane)
