@@ -84,6 +84,7 @@ static int fwd_nt_from_env() {
 static const int FWD_NT = fwd_nt_from_env();
 inline int seg_blocks(int T) { return SEG_SITES / T; }
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
+constexpr double DENSE_SCAN_MAX_NONHOM = 0.08;  // static plan: share of het + missing sites above which the hybrid plan's beta scan is the structured one
 
 struct DevBuf {
     void* p = nullptr;
@@ -152,6 +153,7 @@ struct phk_handle {
     hipStream_t side = nullptr;  // second stream of the segmented plan
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
+    double nonhom_frac = 0.0;  // share of the observation matrix that is het or missing (counted by pack_kernel)
     int asm_run = 0;  // phk_set_asm_run (developer builds with -DPHK_ASM_RUN=1)
     int budget_num[3] = {1, 1, 1}, budget_den[3] = {1, 1, 1};  // phk_set_loop_budget_scale (tests): forward kernel, backward kernel, beta scan
     int poison = 0;  // diagnostic: fill the scratch buffers with this byte before every launch sequence (PHK_POISON=255: NaN patterns)
@@ -317,7 +319,13 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         // the state count allows (2 up to K = 32, 4 at K = 64: round 5 -- the rule used to ask for 2 and K = 64 never
         // got a hybrid plan, 157 ms at cfg4 against the tuner's 146)
         const int Rseg = (!h->dbl && h->K / p.R == 8 && valid_Rs(h, p.R)) ? p.R : 4;
-        const int Rscan = dense_scan_ok(h) ? 16 : smallest_scan_R(h);
+        // ... unless the rows are dense in het / missing sites: the dense scan's time grows with them (6.6 ms at 2 % non-hom sites,
+        // 12-14 at 11 % at cfg2, where the forward kernel beside it takes 9-10) while the structured scan's does not (13), and the
+        // dense scan's 4,328 waves hold the wave slots the sweeps want once it outlasts the forward kernel: the static plan at
+        // 10 % hets measured 39.3 ms per step with the dense scan against the tuner's 32.3 with the structured one
+        // (profiles/r06_ab_experiments.txt item 9).  The tuner switches between 5 % and 10 % hets; so does this rule.
+        const bool dense_rows = h->nonhom_frac > DENSE_SCAN_MAX_NONHOM;
+        const int Rscan = (dense_scan_ok(h) && !dense_rows) ? 16 : smallest_scan_R(h);
         if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, Rseg) &&
             valid_T(h->K, Rseg, 8) && Rscan > 0) {
             p.hybrid_first = first;
@@ -813,10 +821,16 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     }
     if (rc == PHK_OK) {
         const int64_t total = N * h->Lw;
-        hipLaunchKernelGGL(phk::pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dsrc, N, L, h->packed, h->Lw);
+        unsigned long long* d_cnt = nullptr;  // sites that are not hom: what the static plan's choice of the beta scan depends on
+        unsigned long long cnt = 0;
+        if (hipMalloc((void**)&d_cnt, sizeof(cnt)) != hipSuccess || hipMemset(d_cnt, 0, sizeof(cnt)) != hipSuccess) d_cnt = nullptr;
+        hipLaunchKernelGGL(phk::pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dsrc, N, L, h->packed, h->Lw, d_cnt);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess && d_cnt) e = hipMemcpy(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost);
+        if (d_cnt) (void)hipFree(d_cnt);
         if (e != hipSuccess) rc = fail(PHK_EHIP, "pack kernel: %s", hipGetErrorString(e));
+        h->nonhom_frac = (double)cnt / ((double)N * (double)L);
     }
     if (staged) (void)hipFree(staged);
     if (rc != PHK_OK) {

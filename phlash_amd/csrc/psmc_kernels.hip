@@ -3160,8 +3160,10 @@ __global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict_
     emit(8, mul(4, 4));
 }
 
+// (nonhom: optional device counter of the sites that are not hom -- the one property of the data the static plan looks at, see
+// phk_api.hip static_plan)
 __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t L, uint32_t* __restrict__ out,
-                            int64_t Lw) {
+                            int64_t Lw, unsigned long long* __restrict__ nonhom) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * Lw) return;
     const int64_t row = idx / Lw, w = idx - row * Lw;
@@ -3177,6 +3179,13 @@ __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t 
         word |= code << (2 * j);
     }
     out[idx] = word;
+    if (nonhom != nullptr) {
+        const int64_t left = L - w * 16;  // sites of this word inside the row
+        uint32_t nh = (word | (word >> 1)) & 0x55555555u;
+        if (left < 16) nh &= left > 0 ? ((1u << (2 * left)) - 1u) : 0u;
+        const int n = __builtin_popcount(nh);
+        if (n) atomicAdd(nonhom, (unsigned long long)n);
+    }
 }
 #endif  // PHK_WITH_PACK
 
