@@ -236,7 +236,7 @@ def _full_size_case(K, B, S, L, W, *, seed=0, expect_slabs=False, het_rate=None,
     parameters; gradient rows within a * own + c * whole-row), gradient call == no-gradient call, and
     the two size-independent identities of a W = 0 sweep over the whole batch."""
     data, P, eng = _setup(K, B, S, L, W, False, seed=seed, het_rate=het_rate)
-    if static_plan:  # the static rule's plan instead of the tuner's (at cfg2: the dense beta scan whatever the het rate)
+    if static_plan:  # the static rule's plan instead of the tuner's
         eng.set_deterministic(True)
     inds = torch.arange(S, device="cuda")
     ll, g = eng.run(P, inds, W, grad=True)
@@ -312,13 +312,17 @@ def test_whole_chromosome_row_as_the_held_out_kernel_sees_it():
     assert not eng.underflow_risk()
 
 
-def test_cfg2_full_size_at_10pct_hets():
-    """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 10 % i.i.d. hets + 1 % missing: the hybrid
-    plan's dense beta scan over the segment-swept range takes het-terminated dense steps in 84 % of its words; oracle
-    sample on both sides of the split, gradient call == no-gradient call, the W = 0 identities over the whole batch."""
-    eng = _full_size_case(16, 100, 500, 60_000, 500, het_rate=0.10, seed=5, static_plan=True)
+@pytest.mark.parametrize("het_rate,first,r_scan", [(0.06, 32700, 16), (0.10, 32768, 2)])
+def test_cfg2_full_size_at_human_het_rates_static_plan(het_rate, first, r_scan):
+    """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 6 % / 10 % i.i.d. hets + 1 % missing under the STATIC
+    plan (deterministic mode).  At 7 % non-hom sites the hybrid plan's beta scan is the dense one (het-terminated dense steps in
+    most of its words, split rounded to whole chunks); above 8 % -- round 6: pack_kernel counts the sites that are not hom -- the
+    static rule takes the structured two-lane scan as the tuner does (the dense scan outlasts the forward kernel there and holds the
+    sweeps' wave slots: 39 instead of 32 ms per step).  Oracle sample on both sides of the split, gradient call == no-gradient
+    call, the W = 0 identities over the whole batch."""
+    eng = _full_size_case(16, 100, 500, 60_000, 500, het_rate=het_rate, seed=5, static_plan=True)
     plan = eng.get_plan()
-    assert plan.get("hybrid_first") == 32700 and plan["R_scan"] == 16, plan
+    assert plan.get("hybrid_first") == first and plan["R_scan"] == r_scan, plan
     assert not eng.underflow_risk()
 
 
