@@ -284,7 +284,7 @@ constexpr float RATIO_MIN_EMIS0 = 0x1p-64f;
 #define PHK_FOLD 1  // A/B: 0 = no float32 kernel folds its hom emission into the factors
 #endif
 #ifndef PHK_ASM_RUN
-#define PHK_ASM_RUN 0  // 1 (developer builds: scripts/ab_build.sh <tag> f32 16 -DPHK_ASM_RUN=1): the K = 16, R = 2 float32 sweeps run their
+#define PHK_ASM_RUN 0  // 1 (developer builds: make -C phlash_amd/csrc OUT=exp/libphk_asm.so OBJDIR=/tmp/build_asm EXTRA=-DPHK_ASM_RUN=1, run with PHK_LIB): the K = 16, R = 2 float32 sweeps run their
                        // hot blocks through the generated instruction sequence sweep_run_k16r2.inc (scripts/gen_sweep_asm.py) when the
                        // handle asks for it (phk_set_asm_run).  Bit-identical to the C++ body and 1-2 % SLOWER than it
                        // (profiles/r06_ab_experiments.txt item 8), hence not in the shipped library
