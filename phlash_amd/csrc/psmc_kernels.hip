@@ -2749,6 +2749,13 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #if PHK_BSCAN_PRIO
     __builtin_amdgcn_s_setprio(PHK_BSCAN_PRIO);
+#else
+    // The STRUCTURED scan at K = 16 float32 (two or more states per lane) is only ever picked where the dense one loses -- rows
+    // dense in het / missing sites -- and there it is the longest kernel of the forward phase (541 lone waves, 13.1 ms at cfg2
+    // against a forward kernel of 10.0, whose waves share its SIMDs): the segment sweep cannot start before it ends.  Its waves
+    // therefore outrank the forward kernel's (priority 1): cfg2 at 10 % hets 32.26 -> 31.65 ms per step, forward kernel 10.2 ->
+    // 10.9 ms, backward phase 21.85 -> 20.5 (profiles/r06_ab_experiments.txt item 10).
+    if constexpr (K == 16 && sizeof(real) == 4 && !has_dense<real, K, R>()) __builtin_amdgcn_s_setprio(2);
 #endif
     const int64_t nseq = A.B * A.S;
     const int rank = threadIdx.x & (R - 1);
