@@ -84,7 +84,8 @@ static int fwd_nt_from_env() {
 static const int FWD_NT = fwd_nt_from_env();
 inline int seg_blocks(int T) { return SEG_SITES / T; }
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
-constexpr double DENSE_SCAN_MAX_NONHOM = 0.08;  // static plan: share of het + missing sites above which the hybrid plan's beta scan is the structured one
+constexpr double DENSE_SCAN_MAX_NONHOM = 0.13;  // static plan: share of het + missing sites above which the hybrid plan's beta scan is the structured one
+constexpr double SCAN_PRIO_MIN_NONHOM = 0.045;  // share of het + missing sites above which the dense beta scan's waves outrank the forward kernel's
 
 struct DevBuf {
     void* p = nullptr;
@@ -319,11 +320,11 @@ Plan static_plan(const phk_handle* h, int64_t nseq, int64_t W) {
         // the state count allows (2 up to K = 32, 4 at K = 64: round 5 -- the rule used to ask for 2 and K = 64 never
         // got a hybrid plan, 157 ms at cfg4 against the tuner's 146)
         const int Rseg = (!h->dbl && h->K / p.R == 8 && valid_Rs(h, p.R)) ? p.R : 4;
-        // ... unless the rows are dense in het / missing sites: the dense scan's time grows with them (6.6 ms at 2 % non-hom sites,
-        // 12-14 at 11 % at cfg2, where the forward kernel beside it takes 9-10) while the structured scan's does not (13), and the
-        // dense scan's 4,328 waves hold the wave slots the sweeps want once it outlasts the forward kernel: the static plan at
-        // 10 % hets measured 39.3 ms per step with the dense scan against the tuner's 32.3 with the structured one
-        // (profiles/r06_ab_experiments.txt item 9).  The tuner switches between 5 % and 10 % hets; so does this rule.
+        // ... unless the rows are very dense in het / missing sites: the dense scan's time grows with them (6.6 ms at 2 % non-hom
+        // sites, 12-14 at 11 % at cfg2, where the forward kernel beside it takes 9-10) while the structured scan's does not (13).
+        // Once the dense scan outlasts the forward kernel its 4,328 waves hold the wave slots the sweeps want: a cliff between 6 %
+        // and 8 % non-hom sites (cfg2: 30.5 -> 36.9 ms per step) that raising the scan's wave priority (scan_prio_for) moves out
+        // to where the structured scan is the faster one anyway -- 16 % (profiles/r06_ab_experiments.txt item 10).
         const bool dense_rows = h->nonhom_frac > DENSE_SCAN_MAX_NONHOM;
         const int Rscan = (dense_scan_ok(h) && !dense_rows) ? 16 : smallest_scan_R(h);
         if (p.T == 8 && h->L >= 8192 && units >= 8 && first > 0 && nseq - first > per_round / 20 && valid_Rs(h, Rseg) &&
@@ -411,6 +412,20 @@ int ensure_part(phk_handle* h, int64_t nloc, int64_t units) {
     return h->part.ensure((size_t)std::max<int64_t>(units - 1, 1) * (size_t)nloc * 6 * h->K * real_size(h));
 }
 
+// s_setprio of the beta scan's waves (KArgs::scan_prio).  They share SIMDs with the forward kernel's, which run at PHK_FWD_PRIO = 1
+// because on rows like the headline's (2 % non-hom sites) the forward kernel is the longer of the two (9.1 ms against 6.6).  The dense
+// scan's time grows with the non-hom sites, and from about 7 % on it is the one that ends last -- and holds the segment sweep up.
+// Measured at cfg2, ms per step, dense scan at priority 0 / 2 and the structured scan (priority 0; at 2 it starves the forward
+// kernel: +2 ms): 2 % hets 29.4 / 29.7 / 31.4, 5 % 30.5 / 30.7 / 31.7, 7 % 36.9 / 30.7 / 31.8, 10 % 37.2 / 31.9 / 32.2,
+// 15 % 39.5 / 33.0 / 33.0, 20 % 41.5 / 36.8 / 33.1 (profiles/r06_ab_experiments.txt item 10).
+int scan_prio_for(const phk_handle* h, const Plan& plan) {
+    if (const char* env = std::getenv("PHK_SCAN_PRIO")) {  // developer override "dense:structured" for A/B runs
+        int d = 0, s = 0;
+        if (std::sscanf(env, "%d:%d", &d, &s) == 2) return plan.R2 == 16 ? d : s;
+    }
+    return (plan.R2 == 16 && !plan.segmented && h->nonhom_frac > SCAN_PRIO_MIN_NONHOM) ? 2 : 0;
+}
+
 // Enqueue one evaluation of `a` (ll, grad and scratch pointers set by the caller) under `plan`.
 // e_mid, if given, is recorded after the forward kernel.
 int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, bool want_grad, hipStream_t st,
@@ -446,6 +461,7 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         a1.seq_end = plan.hybrid_first;
         a2.seq_begin = plan.hybrid_first;
         a2.seq_end = nseq;
+        a2.scan_prio = scan_prio_for(h, plan);
         const int Rf = plan.R1 ? plan.R1 : plan.R;
         const int units = (int)n_units(h, plan.T, a.W);
         if (int rc = ensure_part(h, nseq - plan.hybrid_first, units); rc != PHK_OK) return rc;
@@ -489,7 +505,9 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
     e = l.fwd(plan.R1, plan.T, h->nrm, true, a, nt, st);
     if (e != hipSuccess) return fail(PHK_EHIP, "forward kernel launch (K=%d R=%d T=%d): %s", K, plan.R1, plan.T, hipGetErrorString(e));
     if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
-    e = l.bscan(plan.R2, h->nrm, a, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
+    phk::KArgs as = a;
+    as.scan_prio = scan_prio_for(h, plan);
+    e = l.bscan(plan.R2, h->nrm, as, seg_sites, h->bseg.p, (int32_t*)h->fseg.p, nt, h->side);
     if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
     HIP_TRY(hipEventRecord(h->ev_join, h->side));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1344,6 +1362,7 @@ static int loglik_impl(phk_handle* h, const void* params, int64_t pstride_b, int
         // the pre-folded blocks are laid out like the parameter blocks, five rows instead of seven
         for (int i = 0; i < 4; ++i) a.loop_budget[i] = INT32_MAX;  // enqueue() sets the plan's values
         a.asm_run = h->asm_run;
+        a.scan_prio = 0;  // enqueue() sets the plan's value
         a.pfstride_b = pstride_b / 7 * 5;
         a.pfstride_s = pstride_s / 7 * 5;
         a.prefold = prefold ? prefold + (b0 * a.pfstride_b + s0 * a.pfstride_s) : nullptr;

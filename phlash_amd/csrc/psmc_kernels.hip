@@ -50,9 +50,6 @@
 #ifndef PHK_SEG_PRIO
 #define PHK_SEG_PRIO 0  // s_setprio of the segment sweep's waves (they share SIMDs with the serial sweep's in the hybrid plan)
 #endif
-#ifndef PHK_BSCAN_PRIO
-#define PHK_BSCAN_PRIO 0  // s_setprio of the beta scan's waves (they share SIMDs with the forward kernel's)
-#endif
 #ifndef PHK_FWD_PRIO
 #define PHK_FWD_PRIO 1  // s_setprio of the forward kernel's waves where they are the step's critical path (checkpointing, more than one state per lane): the beta scan's waves of the hybrid plan share their SIMDs and finish 3 ms earlier; cfg2 forward 9.39 -> 9.10 ms, 3 = 1 (r05_ab_experiments.txt item 17)
 #endif
@@ -981,6 +978,7 @@ struct KArgs {
     // wave spin until the watchdog takes the GPU away.  [0] forward kernel (outer iterations: one per 64-site piece or per
     // block of a ragged piece), [1] serial sweep (blocks), [2] beta scan (pieces / words), [3] one unit of the segment sweep (blocks).
     int32_t loop_budget[4];
+    int32_t scan_prio;  // s_setprio of the beta scan's waves (0..3)
     int32_t asm_run;  // 1: the K = 16, R = 2 float32 sweeps run their hot blocks through the hand-written sequence (0: the C++ body; tests)
 };
 
@@ -2747,16 +2745,11 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
     using V = typename L::V;
     constexpr int SPL = L::SPL, NP = L::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-#if PHK_BSCAN_PRIO
-    __builtin_amdgcn_s_setprio(PHK_BSCAN_PRIO);
-#else
-    // The STRUCTURED scan at K = 16 float32 (two or more states per lane) is only ever picked where the dense one loses -- rows
-    // dense in het / missing sites -- and there it is the longest kernel of the forward phase (541 lone waves, 13.1 ms at cfg2
-    // against a forward kernel of 10.0, whose waves share its SIMDs): the segment sweep cannot start before it ends.  Its waves
-    // therefore outrank the forward kernel's (priority 1): cfg2 at 10 % hets 32.26 -> 31.65 ms per step, forward kernel 10.2 ->
-    // 10.9 ms, backward phase 21.85 -> 20.5 (profiles/r06_ab_experiments.txt item 10).
-    if constexpr (K == 16 && sizeof(real) == 4 && !has_dense<real, K, R>()) __builtin_amdgcn_s_setprio(2);
-#endif
+    // the scan's wave priority is a launch argument (phk_api.hip: scan_prio_for): its waves share SIMDs with the forward kernel's
+    // (priority PHK_FWD_PRIO), and which of the two kernels should win the issue slots depends on which one the rows make longer
+    if (A.scan_prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (A.scan_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (A.scan_prio == 1) __builtin_amdgcn_s_setprio(1);
     const int64_t nseq = A.B * A.S;
     const int rank = threadIdx.x & (R - 1);
     // (idle waves leave, lane groups are mapped to sequences as in fwd_kernel: see map_group)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Here (build container), after the round's evidence script (scripts/dev/r5_final.sh a / b) ran on the GPU box: copy the round's evidence from gpurun_out/
+# Here (build container), after the round's evidence script (scripts/dev/r6_final.sh) ran on the GPU box: copy the round's evidence from gpurun_out/
 # (scratch) into profiles/ (tracked).   scripts/collect_round_artifacts.sh r04
 TAG=${1:-r04}
 for t in cfg2 cfg3 cfg4 cfg5 prod prod_het10 prod_sim; do

@@ -312,14 +312,15 @@ def test_whole_chromosome_row_as_the_held_out_kernel_sees_it():
     assert not eng.underflow_risk()
 
 
-@pytest.mark.parametrize("het_rate,first,r_scan", [(0.06, 32700, 16), (0.10, 32768, 2)])
+@pytest.mark.parametrize("het_rate,first,r_scan", [(0.06, 32700, 16), (0.10, 32700, 16), (0.20, 32768, 2)])
 def test_cfg2_full_size_at_human_het_rates_static_plan(het_rate, first, r_scan):
-    """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 6 % / 10 % i.i.d. hets + 1 % missing under the STATIC
-    plan (deterministic mode).  At 7 % non-hom sites the hybrid plan's beta scan is the dense one (het-terminated dense steps in
-    most of its words, split rounded to whole chunks); above 8 % -- round 6: pack_kernel counts the sites that are not hom -- the
-    static rule takes the structured two-lane scan as the tuner does (the dense scan outlasts the forward kernel there and holds the
-    sweeps' wave slots: 39 instead of 32 ms per step).  Oracle sample on both sides of the split, gradient call == no-gradient
-    call, the W = 0 identities over the whole batch."""
+    """cfg2 (100 particles x 500 chunks x 60,000 + 500 sites) on rows with 6 % / 10 % / 20 % i.i.d. hets + 1 % missing under the
+    STATIC plan (deterministic mode).  Up to 13 % non-hom sites (pack_kernel counts them) the hybrid plan's beta scan is the dense
+    one (het-terminated dense steps in most of its words, split rounded to whole chunks) -- above 4.5 % with its waves at a higher
+    priority than the forward kernel's, without which it outlasts the forward kernel and holds the sweeps' wave slots (37 instead of
+    31 ms per step at 10 % hets); beyond, the structured two-lane scan, whose time does not grow with the hets
+    (profiles/r06_ab_experiments.txt item 10).  Oracle sample on both sides of the split, gradient call == no-gradient call, the
+    W = 0 identities over the whole batch."""
     eng = _full_size_case(16, 100, 500, 60_000, 500, het_rate=het_rate, seed=5, static_plan=True)
     plan = eng.get_plan()
     assert plan.get("hybrid_first") == first and plan["R_scan"] == r_scan, plan
