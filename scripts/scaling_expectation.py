@@ -121,6 +121,8 @@ def main():
 
     res["build"] = build_id()  # (bench.py: scaling_expectation.build_matches)
     print(json.dumps(res, indent=1))
+    sys.stdout.flush()
+    os._exit(0)  # (RCCL's version banner sits in the C stdio buffer of this process and would be flushed behind the JSON at a normal exit)
 
 
 if __name__ == "__main__":
