@@ -172,3 +172,19 @@ def test_sweep_block_loops_stay_out_of_scratch():
             assert blk["n"] < 1500 and blk["scratch"] <= allowed, (K, R, seg, blk)
             checked += 1
     assert checked == 6
+
+
+def test_static_profile_files_bench_reads_are_well_formed_and_name_one_build():
+    """bench.py quotes profiles/pmc_summary.json (roofline.traffic, the issue floor) and profiles/scaling_expectation.json in its
+    line and marks them with *_build_matches: both must parse as ONE json document (a launcher banner once trailed the second) and
+    carry the sha256 of the library they were measured with -- the same one, so that a line never mixes two builds' figures."""
+    import json
+
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+    exp = json.load(open(os.path.join(ROOT, "profiles", "scaling_expectation.json")))
+    shas = [pmc.get("lib_sha256"), (exp.get("build") or {}).get("lib_sha256")]
+    assert all(isinstance(s, str) and re.fullmatch(r"[0-9a-f]{64}", s) for s in shas), shas
+    assert shas[0] == shas[1], shas
+    assert {"cfg2", "cfg3", "prod"} <= set(exp["bench_expectation"]), list(exp["bench_expectation"])
+    for cfg, tab in exp["bench_expectation"].items():
+        assert {"N=1", "N=2", "N=4", "N=8"} <= set(tab), (cfg, list(tab))
