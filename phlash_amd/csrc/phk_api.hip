@@ -476,9 +476,6 @@ int enqueue(phk_handle* h, const Launchers& l, phk::KArgs a, const Plan& plan, b
         if (e != hipSuccess) return fail(PHK_EHIP, "beta-scan kernel launch (hybrid, K=%d R=%d): %s", K, plan.R2, hipGetErrorString(e));
         if (e_mid) HIP_TRY(hipEventRecord(e_mid, st));
         HIP_TRY(hipEventRecord(h->ev_fwd, st));
-#ifdef PHK_EXP_EARLY_SWEEP  // timing experiment only (wrong results unless the checkpoints of the previous call are this call's)
-        if (!std::getenv("PHK_EARLY_SWEEP"))
-#endif
         HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fwd, 0));
         e = l.bwd(plan.R3, plan.T, h->nrm, a2, units, nt, h->side);
         if (e == hipSuccess) e = l.fin(a2, units, h->side);
