@@ -258,7 +258,8 @@ hipError_t PHK_CAT(launch_bscan_, PHK_SUFFIX)(int R, int nrm, const KArgs& a, in
 #if PHK_BWD_PART
 hipError_t PHK_CAT(launch_finalize_, PHK_SUFFIX)(const KArgs& a, int units, hipStream_t st) {
     const int64_t n = ((a.seq_end > 0 ? a.seq_end : a.B * a.S) - a.seq_begin) * 7 * KK;
-    hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, KK, units);
+    static_assert(KK % 4 == 0, "grad_finalize_kernel takes four states per thread");
+    hipLaunchKernelGGL((grad_finalize_kernel<real_t>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, a, KK, units);
     {  // (sequences whose waves swept in the folded form: plain sums -> the caller's gradient)
         const int64_t m = n / 7;
         hipLaunchKernelGGL((grad_unfold_kernel<real_t>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, a, KK);

@@ -3020,35 +3020,56 @@ __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void b
 // gacc [B*S, 6, K] (unit 0) + part [units - 1, range, 6, K] (the other units, added in unit order:
 // the result does not depend on the order in which the units ran) + bpi [B*S, K] -> grad [B*S, 7, K]
 template <typename real>
+struct alignas(4 * sizeof(real)) Quad {
+    real x[4];
+};
+template <typename real>
 __global__ void grad_finalize_kernel(KArgs A, int K, int units) {
-    // one thread per gradient entry (sequence, row, state): consecutive threads read consecutive addresses of every
-    // unit's slot (round 3 had one thread per (sequence, state) walking six rows: 115 us at the reference's production
-    // shape, 2,500 sequences x 196 units; the 188 MB of partial sums are what bounds this kernel)
+    // one thread per FOUR consecutive gradient entries (sequence, row, states k .. k + 3; K is a multiple of 4): consecutive
+    // threads read consecutive 16-byte pieces of every unit's slot.  The partial sums are what bounds this kernel (cfg2: 777 MB,
+    // prod: 188 MB); with one entry per thread (rounds 3-5; round 3 had one thread per (sequence, state) walking six rows) it
+    // read them at 3.1 TB/s.  Each entry is summed in unit order as before: the same bits.
     const int64_t seq_hi = A.seq_end > 0 ? A.seq_end : A.B * A.S;
     const int64_t nloc = seq_hi - A.seq_begin;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nloc * 7 * K) return;
-    const int64_t sl = idx / (7 * K);
-    const int rk = (int)(idx - sl * 7 * K);  // r * K + k
+    const int Q = 7 * K / 4;  // quads per sequence
+    if (idx >= nloc * Q) return;
+    const int64_t sl = idx / Q;
+    const int rk = 4 * (int)(idx - sl * Q);  // r * K + k of the first entry
     const int64_t seq = A.seq_begin + sl;
     const int64_t ss = seq / A.B, bb = seq - ss * A.B;  // chunk-major order (see SeqMap); grad in the caller's
     const real* p = (const real*)A.params + bb * A.pstride_b + ss * A.pstride_s;
     real* out = (real*)A.grad + (bb * A.S + ss) * 7 * K;
     const bool dl = A.grad_dlog != 0;
+    Quad<real> o;
     if (rk >= 6 * K) {  // the pi row
-        const double bp = A.bpi[seq * K + (rk - 6 * K)];
-        out[rk] = (real)(dl ? bp * (double)p[rk] : bp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double bp = A.bpi[seq * K + (rk - 6 * K) + i];
+            o.x[i] = (real)(dl ? bp * (double)p[rk + i] : bp);
+        }
+        *(Quad<real>*)(out + rk) = o;
         return;
     }
-    double sum = A.gacc[seq * 6 * K + rk];
+    double sum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] = A.gacc[seq * 6 * K + rk + i];
     const real* pt = (const real*)A.part + sl * 6 * K + rk;
+#pragma unroll 4
     for (int u = 1; u < units; ++u) {
-        sum += (double)*pt;
+        const Quad<real> q = *(const Quad<real>*)pt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] += (double)q.x[i];
         pt += nloc * 6 * K;
     }
-    if (A.aux[seq].folded) out[rk] = (real)sum;  // sums of the folded form: grad_unfold_kernel converts them in place
-    else if (rk < 4 * K) out[rk] = (real)(dl ? sum * (double)p[rk] : sum);
-    else out[rk] = (real)(dl ? sum : sum / (double)p[rk]);
+    const bool folded = A.aux[seq].folded != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (folded) o.x[i] = (real)sum[i];  // sums of the folded form: grad_unfold_kernel converts them in place
+        else if (rk < 4 * K) o.x[i] = (real)(dl ? sum[i] * (double)p[rk + i] : sum[i]);
+        else o.x[i] = (real)(dl ? sum[i] : sum[i] / (double)p[rk + i]);
+    }
+    *(Quad<real>*)(out + rk) = o;
 }
 
 // Segment sweep, folded form (see bwd_kernel): the six rows grad_finalize_kernel left as plain sums -> the caller's
