@@ -83,6 +83,9 @@ def parse():
                     "put two ranks on one GPU)")
     ap.add_argument("--het-rate", type=float, default=None, help="i.i.d. rows with this het rate (+1 %% missing) "
                     "instead of rows simulated from the HMM at theta = 1e-2 (which have ~1 %% hets)")
+    ap.add_argument("--mask-frac", type=float, default=0.0, help="with --het-rate: this share of every row is masked (missing) in runs "
+                    "of --mask-run windows on average, as an accessibility mask leaves them (on top of the 1 %% of single missing windows)")
+    ap.add_argument("--mask-run", type=int, default=200)
     ap.add_argument("--theta", type=float, default=1e-2, help="theta = rho per window of the simulated rows")
     ap.add_argument("--same-plan", type=int, default=1, help="N > 1: install rank 0's tuned plan on every rank (default 1)")
     ap.add_argument("--double", action="store_true", help="float64 kernels (default float32)")
@@ -445,8 +448,17 @@ def main():
         g = np.random.default_rng(1000 + rank)
         data = (g.random((S_rows, W + L), dtype=np.float32) < a.het_rate).astype(np.int8)
         data.flat[g.integers(0, data.size, size=int(0.01 * data.size))] = -1
-        data[:, 0] = np.maximum(data[:, 0], 0)
         data_note = f"i.i.d. Bernoulli({a.het_rate:g}) hets + 1 % missing"
+        if a.mask_frac > 0:  # masked stretches: geometric run lengths of mean --mask-run, geometric gaps for the share asked
+            gap = a.mask_run * (1.0 - a.mask_frac) / a.mask_frac
+            for r in range(data.shape[0]):
+                pos = int(g.geometric(1.0 / gap))
+                while pos < data.shape[1]:
+                    n = int(g.geometric(1.0 / a.mask_run))
+                    data[r, pos:pos + n] = -1
+                    pos += n + int(g.geometric(1.0 / gap))
+            data_note += f" + {a.mask_frac:g} of every row masked in runs of {a.mask_run} windows on average"
+        data[:, 0] = np.maximum(data[:, 0], 0)
     else:
         data = simulate_chunks(K, S_rows, W + L, seed=1000 + rank, theta=a.theta, rho=a.theta)
         data_note = f"rows simulated from the default {K}-state HMM at theta = rho = {a.theta:g} per window + 1 % missing"
