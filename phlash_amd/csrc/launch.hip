@@ -32,14 +32,16 @@ namespace phk {
 using real_t = PHK_REAL;
 constexpr int KK = PHK_K;
 
-static size_t lds_bytes(int R, int nt) {
+static size_t lds_bytes(int R, int nt, bool mask_runs = false) {
     const int spl = KK / R;
     const int erow = 2 * ((spl + 1) / 2);
     const int w = (int)(sizeof(real_t) / 4);
     int raw = 3 * erow;  // per-thread emission table, padded as Lane::ETAB_STRIDE
     const int dw = raw * w;
     if (dw % 4 == 0 && (dw / 4) % 2 == 0) raw += 4 / w;
-    return (size_t)raw * nt * sizeof(real_t);
+    size_t bytes = (size_t)raw * nt * sizeof(real_t);
+    if (mask_runs && has_dense<real_t, KK, 16>() && R == 16) bytes += (size_t)nt * DENSE_Q8_STRIDE * sizeof(float);  // DenseOps::q8 (the *_mr kernels)
+    return bytes;
 }
 
 #if PHK_FWD_PART || PHK_LAT_PART
@@ -49,6 +51,16 @@ static hipError_t fwd_rtn(bool ckpt, const KArgs& a, int nt, hipStream_t st) {
     const int spb = nt / R;  // sequences per workgroup
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
     const size_t lds = lds_bytes(R, nt);
+    if constexpr (has_dense<real_t, KK, R>() && NRM == 4) {  // rows with runs of missing sites: the kernels that step over them (see fwd_kernel_mr)
+        if (a.mask_runs) {
+            const size_t lds_mr = lds_bytes(R, nt, true);
+            if (ckpt)
+                hipLaunchKernelGGL((fwd_kernel_mr<real_t, KK, R, T, NRM, true>), grid, block, lds_mr, st, a);
+            else
+                hipLaunchKernelGGL((fwd_kernel_mr<real_t, KK, R, T, NRM, false>), grid, block, lds_mr, st, a);
+            return hipGetLastError();
+        }
+    }
     if (ckpt)
         hipLaunchKernelGGL((fwd_kernel<real_t, KK, R, T, NRM, true>), grid, block, lds, st, a);
     else
@@ -120,6 +132,12 @@ static hipError_t bscan_rn(const KArgs& a, int64_t seg_sites, void* bseg, int32_
     const int64_t nseq = launch_groups<real_t, KK, R>(a);
     const int spb = nt / R;
     const dim3 grid((unsigned)((nseq + spb - 1) / spb)), block(nt);
+    if constexpr (has_dense<real_t, KK, R>() && NRM == 4) {
+        if (a.mask_runs) {
+            hipLaunchKernelGGL((bscan_kernel_mr<real_t, KK, R, NRM>), grid, block, lds_bytes(R, nt, true), st, a, seg_sites, bseg, fseg);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((bscan_kernel<real_t, KK, R, NRM>), grid, block, lds_bytes(R, nt), st, a, seg_sites, bseg, fseg);
     return hipGetLastError();
 }

@@ -85,6 +85,7 @@ static const int FWD_NT = fwd_nt_from_env();
 inline int seg_blocks(int T) { return SEG_SITES / T; }
 constexpr int TUNE_SITES = 2048;  // sites of the real batch the variant tuner times
 constexpr double DENSE_SCAN_MAX_NONHOM = 0.13;  // static plan: share of het + missing sites above which the hybrid plan's beta scan is the structured one
+constexpr double MASK_RUNS_MIN_SHARE = 0.005;  // share of the sites in all-missing 8-site halves above which the one-state-per-lane kernels step over such halves with one operator (fwd_kernel_mr)
 constexpr double SCAN_PRIO_MIN_NONHOM = 0.045;  // share of het + missing sites above which the dense beta scan's waves outrank the forward kernel's
 
 struct DevBuf {
@@ -155,6 +156,7 @@ struct phk_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fwd = nullptr;
     int profiling = 0;
     double nonhom_frac = 0.0;  // share of the observation matrix that is het or missing (counted by pack_kernel)
+    int mask_runs = 0;  // the rows hold runs of missing sites (pack_kernel: all-missing 8-site halves): KArgs::mask_runs
     int asm_run = 0;  // phk_set_asm_run (developer builds with -DPHK_ASM_RUN=1)
     int budget_num[3] = {1, 1, 1}, budget_den[3] = {1, 1, 1};  // phk_set_loop_budget_scale (tests): forward kernel, backward kernel, beta scan
     int poison = 0;  // diagnostic: fill the scratch buffers with this byte before every launch sequence (PHK_POISON=255: NaN patterns)
@@ -370,7 +372,7 @@ Plan choose_plan(const phk_handle* h, int64_t nseq, int64_t W, int want_grad) {
 }
 
 // The one-state-per-lane kernels (K = 16, float32, rescale interval 4) take their dense hom-run operators from a table
-// built once per launch sequence, one [2 forms][9 powers][16][16] block per parameter block of the launch (18 KB:
+// built once per launch sequence, one [2 forms][10 operators][16][16] block per parameter block of the launch (20 KB; round 6: + the missing-run operator A^8);
 // one per particle when the chunks share it, one per (particle, chunk) otherwise).
 bool dense_capable(const phk_handle* h) { return h->K == 16 && !h->dbl && h->nrm == 4; }
 bool plan_uses_dense(const phk_handle* h, const Plan& p) { return dense_capable(h) && (p.R == 16 || p.R1 == 16 || p.R2 == 16); }
@@ -839,16 +841,20 @@ int phk_create(phk_handle** out, int K, const int8_t* data, int64_t N, int64_t L
     }
     if (rc == PHK_OK) {
         const int64_t total = N * h->Lw;
-        unsigned long long* d_cnt = nullptr;  // sites that are not hom: what the static plan's choice of the beta scan depends on
-        unsigned long long cnt = 0;
+        // [0] sites that are not hom: what the static plan's choice of the beta scan depends on; [1] 8-site halves of a word that
+        // are missing throughout: what decides whether the one-state-per-lane kernels run in their *_mr form (mask_runs)
+        unsigned long long* d_cnt = nullptr;
+        unsigned long long cnt[2] = {0, 0};
         if (hipMalloc((void**)&d_cnt, sizeof(cnt)) != hipSuccess || hipMemset(d_cnt, 0, sizeof(cnt)) != hipSuccess) d_cnt = nullptr;
         hipLaunchKernelGGL(phk::pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, dsrc, N, L, h->packed, h->Lw, d_cnt);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess && d_cnt) e = hipMemcpy(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && d_cnt) e = hipMemcpy(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost);
         if (d_cnt) (void)hipFree(d_cnt);
         if (e != hipSuccess) rc = fail(PHK_EHIP, "pack kernel: %s", hipGetErrorString(e));
-        h->nonhom_frac = (double)cnt / ((double)N * (double)L);
+        h->nonhom_frac = (double)cnt[0] / ((double)N * (double)L);
+        h->mask_runs = (double)cnt[1] * 8.0 > MASK_RUNS_MIN_SHARE * (double)N * (double)L ? 1 : 0;
+        if (const char* env = std::getenv("PHK_MASK_RUNS")) h->mask_runs = std::atoi(env) != 0;  // developer override, A/B runs
     }
     if (staged) (void)hipFree(staged);
     if (rc != PHK_OK) {
@@ -1363,6 +1369,7 @@ static int loglik_impl(phk_handle* h, const void* params, int64_t pstride_b, int
         for (int i = 0; i < 4; ++i) a.loop_budget[i] = INT32_MAX;  // enqueue() sets the plan's values
         a.asm_run = h->asm_run;
         a.scan_prio = 0;  // enqueue() sets the plan's value
+        a.mask_runs = h->mask_runs;
         a.pfstride_b = pstride_b / 7 * 5;
         a.pfstride_s = pstride_s / 7 * 5;
         a.prefold = prefold ? prefold + (b0 * a.pfstride_b + s0 * a.pfstride_s) : nullptr;

@@ -222,6 +222,9 @@ struct Group {
 // ---------------------------------------------------------------------------------------------
 template <typename real, int K, int R>
 constexpr bool has_dense() { return K == 16 && R == 16 && sizeof(real) == 4; }
+// floats per thread of the *_mr dense kernels' LDS slice holding the missing-run operator (DenseOps::q8), behind the workgroup's
+// emission tables: 16 slots, padded to an odd number of 16-byte units (conflict-free ds_read_b128, see Lane::ETAB_STRIDE)
+constexpr int DENSE_Q8_STRIDE = 20;
 
 template <int J>
 __device__ __forceinline__ float row_share(float x) {  // every lane of a 16-lane row reads lane J of its row
@@ -307,6 +310,10 @@ template <>
 struct DenseOps<true> {
     float P[8][16];  // P[n-1] = M_h^n, n = 1..8: slot j of lane i = [j][i] (forward) or [i][j] (beta scan)
     float D16[16];   // M_h^16
+    // (M_h diag(1 / emis0))^8 = A^8, eight MISSING sites in a row (an accessibility mask leaves runs of hundreds): this lane's
+    // sixteen slots in LDS, read when such a half comes up.  In registers (16 more of 221 / 237) the operator cost the forward
+    // kernel of the reference's production shape 0.45 of its 1.93 ms on rows without a single run (r06_ab_experiments.txt item 14).
+    const float* q8;
     float rhet, rmis;  // this lane's state: emis1 / emis0 and 1 / emis0
 };
 
@@ -635,7 +642,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // the prologue of every wave (float64 products over DPP broadcasts: ~5,000 instructions, 1.4 KB of scratch per
     // lane); with all eight powers that prologue outgrew the 2,048-site problem the tuner times these kernels on.
     template <bool NEED16>
-    __device__ __forceinline__ void load_dense(const float* __restrict__ ops, int rank, const bool folded) {
+    __device__ __forceinline__ void load_dense(const float* __restrict__ ops, int rank, const bool folded, float* q8_lds) {
         if constexpr (has_dense<real, K, R>()) {
             const float4* src = (const float4*)(ops + rank * 16);
 #pragma unroll
@@ -659,6 +666,11 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
                     this->D16[4 * q + 3] = v4.w;
                 }
             }
+            if (q8_lds != nullptr) {  // (the *_mr kernels only: see half_step)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ((float4*)q8_lds)[q] = src[9 * 64 + q];
+            }
+            this->q8 = q8_lds;
             // (a folded lane's table already holds the ratios: rows 1 and 2)
             const double e0 = (double)etab[0], e1 = (double)etab[EROW];
             this->rhet = folded ? etab[EROW] : (float)(e1 / e0);
@@ -708,7 +720,7 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
     // Returns the rescale debt of the half (1 per hom site, 16 per het / missing site); `resc(x)` is called after a run
     // of the generic loop whenever the running debt (debt0 + so far) reaches the threshold: it rescales x, books the
     // exponent and returns the debt it leaves (0).
-    template <bool FWD, typename Resc>
+    template <bool FWD, bool MR, typename Resc>
     __device__ __forceinline__ int half_step(float& x, const uint32_t h, const int debt0, Resc&& resc) const {
         if constexpr (has_dense<real, K, R>()) {
             if (__builtin_expect(h == 0u, 1)) {
@@ -738,6 +750,24 @@ struct Lane : DenseOps<has_dense<real, K, R>()> {
 #undef PHK_ONE
                 }
                 return debt0 + 8 + 16;
+            }
+            // eight missing sites: one step by A^8 = (M_h diag(1 / emis0))^8 (either form: the ratio sits between the hom
+            // steps).  Masked stretches of a genome are runs of hundreds of missing windows; site by site they cost one
+            // dense step EACH, eight to sixteen times a hom site (500 x 5 x 100,000 at 7 % hets with a quarter of every
+            // row masked: forward phase 7.2 instead of 3.2 ms).  Only in the kernels
+            // launched for rows that hold such runs (MR: fwd_kernel_mr / bscan_kernel_mr).  A stochastic matrix takes no mass away: debt as for hom sites.
+            if (MR && h == 0xAAAAu) {
+                float Q[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v4 = ((const float4*)this->q8)[q];
+                    Q[4 * q + 0] = v4.x;
+                    Q[4 * q + 1] = v4.y;
+                    Q[4 * q + 2] = v4.z;
+                    Q[4 * q + 3] = v4.w;
+                }
+                x = dense16(x, Q);
+                return debt0 + 8;
             }
             // two or more het / missing sites: by quarters of four sites -- all hom: M_h^4; one such site: 4-way
             // dispatch; more: run by run (a dispatch per run)
@@ -965,7 +995,7 @@ struct KArgs {
     // gacc (it alone touches the sequence's row there); grad_finalize_kernel adds them up in unit order.
     void* part;
     // dense hom-run operators of the one-state-per-lane kernels (K = 16, float32; dense_ops_kernel): per parameter block
-    // [9 powers M_h^1..8, M_h^16][lane 16][slot 16] floats, forward form and beta-scan form; null where those kernels are not used
+    // [10 operators M_h^1..8, M_h^16, (M_h diag(1 / emis0))^8][lane 16][slot 16] floats, forward form and beta-scan form; null where those kernels are not used
     const float* ops_f;
     const float* ops_b;
     // pre-folded factors of every parameter block (float32 kernels; phk_prefold / phk_loglik_prefolded): [B, S|1, 5, K]
@@ -979,6 +1009,7 @@ struct KArgs {
     // block of a ragged piece), [1] serial sweep (blocks), [2] beta scan (pieces / words), [3] one unit of the segment sweep (blocks).
     int32_t loop_budget[4];
     int32_t scan_prio;  // s_setprio of the beta scan's waves (0..3)
+    int32_t mask_runs;  // 1: the rows hold runs of missing sites; the one-state-per-lane kernels are launched in their *_mr form
     int32_t asm_run;  // 1: the K = 16, R = 2 float32 sweeps run their hot blocks through the hand-written sequence (0: the C++ body; tests)
 };
 
@@ -988,7 +1019,7 @@ __device__ __forceinline__ const real* prefold_block(const KArgs& A, int64_t bb,
     if constexpr (sizeof(real) == 4) return A.prefold != nullptr ? (const real*)A.prefold + bb * A.pfstride_b + ss * A.pfstride_s : nullptr;
     else return nullptr;
 }
-constexpr int DENSE_NPOW = 9;
+constexpr int DENSE_NPOW = 10;  // M_h^1 .. M_h^8, M_h^16, (M_h diag(1 / emis0))^8
 constexpr int DENSE_OPS_FLOATS = DENSE_NPOW * 256;  // per parameter block and form
 
 // bits of the sticky device flag word (KArgs::risk)
@@ -1184,612 +1215,20 @@ __device__ __forceinline__ SeqMap map_group(const KArgs& A) {
     return m;
 }
 
+// (MR: the one-state-per-lane kernels of a handle whose rows hold runs of missing sites -- an accessibility mask -- step over eight
+// missing sites with one operator, Lane::half_step.  Kernels of their own, picked by the launcher from KArgs::mask_runs, compiled
+// from the same text: fwd_kernel_body.inc / bscan_kernel_body.inc.)
 template <typename real, int K, int R, int T, int NRM, bool CKPT>
 __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void fwd_kernel(KArgs A) {
-    using L = Lane<real, K, R>;
-    using V = typename L::V;
-    constexpr int SPL = L::SPL, NP = L::NP;
-    static_assert(T <= 16 && 16 % T == 0, "a block's codes must sit in one dword");
-    static_assert(T % NRM == 0, "the rescale schedule must restart with every block");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-#if PHK_FWD_PRIO
-    if constexpr (CKPT && !has_dense<real, K, R>()) __builtin_amdgcn_s_setprio(PHK_FWD_PRIO);
-#endif
-    const int64_t nseq = A.B * A.S;
-    const int rank = threadIdx.x & (R - 1);
-    // A wave none of whose lane groups has a sequence leaves (wave-uniform; these kernels have no barrier).  It must
-    // not run: lane groups without a sequence repeat another sequence's work and, in the lean piece loops, its
-    // stores -- harmless inside a wave that also holds the real group (same wave votes, hence the same dense /
-    // structured steps, the same rescales, the same bits to the same addresses), but a wave made of repeats only
-    // votes among copies of ONE sequence, takes dense steps and rescales where the real group's wave does not, and its
-    // checkpoints and block exponents -- scaled by other powers of two -- would race with the real ones (seen in the
-    // fuzz soak once the dense steps stopped rescaling after every step: the last sequence of a launch came back with
-    // checkpoints of one scaling and exponents of the other).
-    const SeqMap sm = map_group<real, K, R>(A);
-#ifndef PHK_KEEP_IDLE_WAVES  // (diagnostic builds define it to show that the regression test catches the race)
-    if (sm.idle_wave) return;
-#endif
-    const bool active = sm.active;
-    const int64_t bb = sm.bb, ss = sm.ss, seq = sm.seq;
-
-    L lane;
-    V a[NP];
-    lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
-              (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, a);
-    const real* pfb = prefold_block<real>(A, bb, ss);
-    const bool fold_seq = lane.try_fold(pfb != nullptr ? pfb + rank * L::SPL : nullptr);  // (float32: the folded model, see Lane::try_fold)
-    constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.template load_dense<T == 16>(A.ops_f + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
-    const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
-    // Do the four sequences of this wave read ONE observation row (true for every wave of a range of whole particles:
-    // map_group), and are their hom emissions far enough from zero for the het / missing ratios to exist?  Then the codes are scalars and every run of sites is one
-    // dense step (uni_block below).  Other waves keep the wave-vote path.
-    bool uni = false;
-    if constexpr (DENSE && PHK_DENSE_UNI != 0) {
-        const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && (fold_seq || lane.etab[0] > RATIO_MIN_EMIS0)) != 0;
-    }
-    // The other float32 layouts: sequences are stored chunk-major (SeqMap), so a wave holds the particles of ONE chunk,
-    // or of two where it crosses a chunk boundary.  Such a wave (uni2) folds its hom emission into the factors
-    // (Lane::fold_emissions) and takes its codes as scalars: a block of T sites that is hom in both rows -- 85 % of the
-    // blocks at 1 % hets -- runs without a single emission row (no LDS gather, no multiply: a timing-only build of the
-    // one-lane forward kernel without them ran cfg2's forward phase in 8.1 instead of 10.8 ms); any other block takes
-    // the straight-line path with per-lane codes as ever, its rows now the ratios emis1 / emis0, 1 / emis0 and 1.
-    constexpr bool FOLD = !DENSE && (sizeof(real) == 4 || PHK_FOLD_F64 != 0) && PHK_FWD_FOLD != 0;
-    constexpr bool FREG = FOLD && PHK_FWD_HET_REGS != 0;
-    V rhet[NP], rmis[NP];  // FREG: a folded lane's ratio rows emis1 / emis0 and 1 / emis0 (see fold_block)
-    if constexpr (FREG) {
-#pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            rhet[h] = *(const V*)(lane.etab + L::EROW + 2 * h);
-            rmis[h] = *(const V*)(lane.etab + 2 * L::EROW + 2 * h);
-        }
-    }
-    bool uni2 = false, rowB = false;
-    if constexpr (FOLD) {
-        const int sA = __builtin_amdgcn_readfirstlane((int)ss), sB = __builtin_amdgcn_readlane((int)ss, 63);
-        // (a sequence folds whenever its own ratios exist, whatever its wave does: a site's row is then exactly 1 where
-        // the wave-uniform path would have skipped the multiply, so both paths return the same bits)
-        uni2 = __all(((int)ss == sA || (int)ss == sB) && fold_seq) != 0;
-        rowB = (int)ss != sA;
-    }
-
-    int E = 0;
-    // smallest distance to its threshold of any exponent a rescale of this sequence removed: RISK_EXP_* for the
-    // rescales after NRM sites, RISK_EXP_DEFERRED_F32 for the deferred rescales of the dense steps.  ONE variable on
-    // purpose: with two, the compiler sinks the updates into one block behind a select of their ADDRESSES, both stay
-    // in scratch, and every scratch_load's s_waitcnt vmcnt(0) also waits for the observation piece requested ahead
-    // (round 4: 35-42 % of the one-state-per-lane kernels' wave cycles went there)
-    constexpr int RISK_EXP = sizeof(real) == 4 ? RISK_EXP_F32 : RISK_EXP_F64;
-    int ex_slack = 1 << 20;
-    int hom_run = 0;  // dense kernels: rescale debt -- hom sites stepped over since the last rescale (uniform path: + 16 per het / missing site)
-    int eb_min = 0;   // smallest exponent total of any checkpoint block
-    double llW = 0.0;
-    // Block loop bookkeeping is kept in 32-bit wave-uniform integers and stepped pointers: in the
-    // latency-bound layout a block is only ~300 cycles of arithmetic, and 64-bit index products or
-    // an integer division per block (the segment test used to be blk % seg_blocks) cost as much.
-    const int nblk = (int)((A.Ltot + T - 1) / T);
-    const int nfull = (int)(A.Ltot / T);                      // blocks [0, nfull) hold T sites
-    const int tail = (int)(A.Ltot - (int64_t)nfull * T);      // sites of the last, partial block
-    const int blkW = A.W > 0 ? (int)((A.W - 1) / T) : -1;     // block holding the warm-up boundary
-    const int iW = A.W > 0 ? (int)((A.W - 1) - (int64_t)blkW * T) : -1;  // ... after its site iW
-    const int64_t ck_step = nseq * K;
-    real* ckp = (real*)A.ckpt + L::ck_lane(nseq, seq, rank);   // this lane's first state in the current block's checkpoint
-    int16_t* ebp = A.eblk + seq;
-    int32_t* esp = A.eseg + seq;
-    int seg_left = 0;  // blocks until the next segment starts
-    // Observation words come in 16-byte pieces (4 words = 64 sites; rows are padded to whole
-    // pieces), requested one piece ahead, and the block loop is nested inside the piece loop.  The
-    // wait for a piece also waits for every store issued before it completes (vmcnt counts stores,
-    // and the checkpoint stores sit in branches the compiler cannot count through): with the
-    // prefetched word carried around a flat block loop that was a full store round trip per block.
-    constexpr int BPC = 64 / T;  // blocks per piece
-    const uint4* pieces = (const uint4*)words;
-    const int npieces = (int)(A.Lw >> 2);
-    uint4 pnext = pieces[0];
-    // land the first piece before the loop (an empty asm that reads it): otherwise "the register of
-    // the current piece may still be in flight" is a state the compiler carries around the block loop,
-    // and it waits (vmcnt) before every block's word select -- which also drains that block's
-    // checkpoint stores.  float32 kernels only: the float64 K = 64 forward kernel (pieces and
-    // parameters loaded straight into AGPRs, scratch in use) returned wrong log-likelihoods with it,
-    // in this form and with an explicit s_waitcnt alike, and passes without.
-    if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));
-    // With checkpoint stores in flight, every wait for a requested piece is a wait for ALL stores issued
-    // before it (one store round trip, ~5,000 cycles under the 2 TB/s this kernel writes: 19 % of a lone
-    // wave's cycles at one wait per 64 sites).  The checkpointing variants that have registers to spare
-    // therefore request FOUR pieces (256 sites) at a time and pay that round trip a quarter as often.
-    constexpr int PPB = ((PHK_FWD_BIG_PIECES == 1 && CKPT && !has_dense<real, K, R>() && SPL * (int)sizeof(real) >= 32) ||
-                         (PHK_FWD_BIG_PIECES == 2 && CKPT && has_dense<real, K, R>())) ? 4 : 1;
-    uint4 nx1 = pnext, nx2 = pnext, nx3 = pnext;
-    if constexpr (PPB == 4) {
-        nx1 = pieces[1 < npieces ? 1 : npieces - 1];
-        nx2 = pieces[2 < npieces ? 2 : npieces - 1];
-        nx3 = pieces[3 < npieces ? 3 : npieces - 1];
-        if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64)
-            asm volatile("" ::"v"(nx1.x), "v"(nx1.y), "v"(nx1.z), "v"(nx1.w), "v"(nx2.x), "v"(nx2.y), "v"(nx2.z), "v"(nx2.w),
-                         "v"(nx3.x), "v"(nx3.y), "v"(nx3.z), "v"(nx3.w));
-    }
-    // One full block of the one-state-per-lane layout (DENSE): sixteen / eight / four / two hom sites for all
-    // four sequences of the wave (wave vote) are ONE dense M_h^n step; one rescale per dense step, or per
-    // group of four sites (the NRM = 4 schedule) where structured steps are needed.  All-hom blocks of 8 sites
-    // are 61 % of the blocks at 5 % hets + 1 % missing, of 16 sites 37 %.  The block's exponent total goes
-    // into eblk as ever; the sweep re-runs blocks in its own scaling and corrects beta by 2^(e_run - e_fwd).
-    auto dense_block = [&](const uint32_t codes) {
-        if constexpr (DENSE) {
-            // A rescale costs as much as the dense step itself (sum butterfly, exponent, multiply: ~90 of ~240 dependent
-            // cycles), and a hom site takes little mass away: along a run of dense steps the state is rescaled once per
-            // PHK_DENSE_RESCALE_SITES sites.  Blocks in between record an exponent of 0; power-of-two scales round
-            // nothing, so the checkpoints and the log-likelihood are the same bits times a power of two.
-            if (T == 16 && PHK_DENSE16 && __all(codes == 0u)) {
-                a[0][0] = dense16(a[0][0], lane.D16);
-                hom_run += 16;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    const int ex = lane.rescale(a);
-                    E += ex;
-                    ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
-                }
-                return;
-            }
-#pragma unroll
-            for (int h8 = 0; h8 < T / 8; ++h8) {
-                if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
-                    a[0][0] = dense16(a[0][0], lane.P[7]);
-                    hom_run += 8;
-                    if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                        hom_run = 0;
-                        const int ex = lane.rescale(a);
-                        E += ex;
-                        ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
-                    }
-                    continue;
-                }
-                hom_run = 0;  // (the groups of four below end in a rescale each)
-#pragma unroll
-                for (int g = 2 * h8; g < 2 * h8 + 2; ++g) {
-                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                    if (__all(c4 == 0u)) {
-                        a[0][0] = dense16(a[0][0], lane.P[3]);
-                    } else {
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                            if (__all(c2 == 0u)) {
-                                a[0][0] = dense16(a[0][0], lane.P[1]);
-                            } else {
-                                real sc;
-                                V e[NP];
-                                lane.emis(c2 & 3, e);
-                                lane.fwd_site(a, e, sc, false);
-                                lane.emis(c2 >> 2, e);
-                                lane.fwd_site(a, e, sc, false);
-                            }
-                        }
-                    }
-                    const int ex = lane.rescale(a);
-                    E += ex;
-                    ex_slack = min(ex_slack, ex - RISK_EXP);
-                }
-            }
-        }
-    };
-    // One full block of a wave whose sequences share their observation row (uni): `rem` holds the block's codes as a
-    // SCALAR.  A run "hom^(n-1), then a het or missing site" is one dense M_h^n step plus one multiply by emis1 / emis0
-    // or 1 / emis0 (Lane::half_step: straight-line code for the all-hom half and for a half with one such site).
-    // Rescales: when the debt (1 per hom site, 16 per het / missing site) reaches PHK_DENSE_RESCALE_SITES, i.e. after
-    // at most 64 hom or 4 other sites as before.  Returns the exponent taken out of the block.
-    auto uni_block = [&](const uint32_t rem) -> int {
-        int dE = 0;
-        if constexpr (DENSE) {
-            float x = a[0][0];
-            auto resc = [&](float& y) -> int {
-                const int ex = lane.rescale1(y);
-                dE += ex;
-                ex_slack = min(ex_slack, ex - RISK_EXP_DEFERRED_F32);
-                return 0;
-            };
-            if (T == 16 && __builtin_expect(rem == 0u, 1)) {
-                x = dense16(x, lane.D16);
-                hom_run += 16;
-            } else {
-                hom_run = lane.template half_step<true>(x, rem & 0xffffu, hom_run, resc);
-                if constexpr (T == 16) {
-                    if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
-                    hom_run = lane.template half_step<true>(x, rem >> 16, hom_run, resc);
-                }
-            }
-            if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
-            a[0][0] = x;
-        }
-        return dE;
-    };
-    // one full block of the other layouts: a straight-line basic block of T sites (no per-site branches), the
-    // emission row of the next site in flight while the current one computes
-    auto straight_block = [&](const uint32_t codes) {
-        V ec[NP];
-        lane.emis(codes & 3, ec);
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            V en[NP];
-            if (i + 1 < T) lane.emis((codes >> (2 * (i + 1))) & 3, en);
-            real sc;
-            const int ex = lane.fwd_site(a, ec, sc, rescale_after<NRM>(i));
-            E += ex;
-            if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
-            if (i + 1 < T) {
-#pragma unroll
-                for (int h = 0; h < NP; ++h) ec[h] = en[h];
-            }
-#if PHK_FWD_SITE_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-    };
-    // Lean piece loop of the DENSE kernels.  A block of this layout is ~500 cycles of arithmetic, and the
-    // general block loop below spent as many again on its per-block tests (full block? warm-up boundary?
-    // segment start? which word of the piece?), on 64-bit per-lane store addresses and on exec-mask branches
-    // around the stores (timing-only builds at 500 x 5 x 100,000: 1.31 of 2.64 ms).  A piece of 64 sites that
-    // holds only full blocks and no warm-up boundary takes this path instead: tests once per piece, the
-    // piece's words rotated through one register, wave-uniform store bases with 32-bit lane offsets, and
-    // stores by every lane (lanes past the last sequence repeat its work bit for bit: same value, same address).
-    constexpr bool LEAN = PPB == 1 && (DENSE ? PHK_DENSE_LEAN != 0 : (PHK_FWD_LEAN != 0 && PHK_EMIS_AHEAD < 2));
-    // (lane offsets of the lean stores are 32-bit BYTE offsets beside a wave-uniform base: the store then takes the
-    // base from SGPRs -- global_store ... v_off, v_data, s[base] -- and costs no address arithmetic per block)
-    const bool lean_ok = LEAN && (A.seg_blocks % BPC) == 0 && nseq * K * (int64_t)sizeof(real) < (int64_t(1) << 31);
-    const unsigned ck_off_e = (unsigned)L::ck_lane(nseq, seq, rank), sq_off_e = (unsigned)seq;
-    const unsigned ck_piece_e = (unsigned)(nseq * 4);  // distance between the pieces of one sequence
-    // (the same in bytes, for uni_piece below)
-    unsigned ck_off = ck_off_e * (unsigned)sizeof(real), sq_off = sq_off_e * 2u;
-    const unsigned ck_piece = ck_piece_e * (unsigned)sizeof(real);
-    int blk = 0;
-    // one lean piece (64 sites, full blocks, no warm-up boundary) of a wave whose sequences share their observation
-    // row: the piece's codes as two scalar 64-bit words, shifted down one block at a time
-    int64_t ck_step_b = ck_step * (int64_t)sizeof(real), eb_step_b = nseq * 2;  // block-to-block distances in bytes ...
-    if constexpr (DENSE) asm volatile("" : "+s"(ck_step_b), "+s"(eb_step_b));     // ... kept in SGPRs, not recomputed per block
-    auto uni_piece = [&](const uint64_t lo, const uint64_t hi) {
-        if constexpr (CKPT) {
-            if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
-                if (seg_left == 0) {
-                    if (active && rank == 0) *esp = E;
-                    esp += nseq;
-                    seg_left = A.seg_blocks;
-                }
-                seg_left -= BPC;
-            }
-        }
-        char* ck_u = (char*)((real*)A.ckpt + (int64_t)blk * ck_step);
-        char* eb_u = (char*)(A.eblk + (int64_t)blk * nseq);
-        // (two halves of BPC / 2 blocks: the codes of a block are the low bits of ONE 64-bit scalar, shifted down)
-#pragma nounroll
-        for (int hf = 0; hf < 2; ++hf) {
-            uint64_t cw = hf == 0 ? lo : hi;
-#pragma nounroll
-            for (int bi = 0; bi < BPC / 2; ++bi) {
-                // (the offsets pass through an empty asm: hoisted out of the loop as 64-bit values they would be added
-                // to the base with a v_lshl_add_u64 per store; seen next to the store they are its 32-bit offset operand)
-                asm volatile("" : "+v"(ck_off), "+v"(sq_off));
-                if constexpr (CKPT) {
-#if !PHK_EXP_NO_CKPT_STORE
-#pragma unroll
-                    for (int i = 0; i < SPL; ++i)
-                        ck_store((real*)(ck_u + (ck_off + (unsigned)(i / 4) * ck_piece + (unsigned)(i % 4) * (unsigned)sizeof(real))), L::get(a, i));
-#endif
-                    ck_u += ck_step_b;
-                }
-                const int dE = uni_block((uint32_t)cw & (uint32_t)((uint64_t(1) << (2 * T)) - 1u));
-                E += dE;
-                if constexpr (CKPT) {
-                    *(int16_t*)(eb_u + sq_off) = (int16_t)dE;
-                    eb_u += eb_step_b;
-                    eb_min = dE < eb_min ? dE : eb_min;
-                }
-                cw >>= 2 * T;
-            }
-        }
-        blk += BPC;
-        if constexpr (CKPT) {
-            ckp += (int64_t)BPC * ck_step;
-            ebp += (int64_t)BPC * nseq;
-        }
-    };
-    auto lean_piece = [&](const int b) { return b + BPC <= nfull && (blkW < b || blkW >= b + BPC); };
-    // (uni2 waves) one full block: `ca` / `cb` are the codes of the wave's two rows as scalars.  Every site takes the
-    // structured step on the folded factors; a site that is not hom in one of the two rows multiplies by its row behind a
-    // wave-uniform branch on one bit (a folded lane's hom row is exactly 1, so the lanes of the other row lose nothing).
-    // At 1 % hets + 1 % missing 96-98 % of the sites take the fall-through: no LDS gather, no multiply.  (Round 4 chose
-    // per BLOCK between an emission-free body and the per-lane-code body: 72-85 % of the blocks.)
-    auto fold_block = [&](const uint32_t ca, const uint32_t cb) {
-        const uint32_t cu = ca | cb;
-        const uint32_t nhm = (cu | (cu >> 1)) & 0x55555555u;  // bit 2i: site i is not hom in one of the wave's rows
-        const uint32_t mine = rowB ? cb : ca;                   // this lane's codes
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            V none[NP];
-            real sc;
-            lane.template fwd_site<false>(a, none, sc, false);
-            if constexpr (FREG) {
-                // round 6: the two ratio rows in registers, het / missing lanes multiply under the exec mask behind one
-                // wave-uniform bit each (round 5: the lane's row from the LDS table, a round trip a lone wave cannot hide)
-#pragma unroll
-                for (int h = 0; h < NP; ++h) asm volatile("" : : "v"(rhet[h]), "v"(rmis[h]));  // (a use on the hot path: see bwd_kernel)
-                if (__builtin_expect((cu >> (2 * i)) & 1u, 0)) {
-                    if (((mine >> (2 * i)) & 3u) == 1u) {
-#pragma unroll
-                        for (int h = 0; h < NP; ++h) a[h] = a[h] * rhet[h];
-                    }
-                }
-                if (__builtin_expect((cu >> (2 * i + 1)) & 1u, 0)) {
-                    if (((mine >> (2 * i)) & 3u) == 2u) {
-#pragma unroll
-                        for (int h = 0; h < NP; ++h) a[h] = a[h] * rmis[h];
-                    }
-                }
-            } else if (__builtin_expect((nhm >> (2 * i)) & 1u, 0)) {
-                V e[NP];
-                lane.emis((mine >> (2 * i)) & 3, e);
-#pragma unroll
-                for (int h = 0; h < NP; ++h) a[h] = a[h] * e[h];
-            }
-            if (rescale_after<NRM>(i)) {
-                const int ex = lane.rescale(a);
-                E += ex;
-                if (NRM > 1) ex_slack = min(ex_slack, ex - RISK_EXP);
-            }
-#if PHK_FWD_SITE_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-    };
-    // (uni2 waves) one lean piece: the codes of the wave's two rows (the same row twice in most waves) as scalars
-    auto fold_piece = [&](const uint64_t loA, const uint64_t hiA, const uint64_t loB, const uint64_t hiB) {
-        if constexpr (CKPT) {
-            if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
-                if (seg_left == 0) {
-                    if (active && rank == 0) *esp = E;
-                    esp += nseq;
-                    seg_left = A.seg_blocks;
-                }
-                seg_left -= BPC;
-            }
-        }
-        real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
-        int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
-#pragma nounroll
-        for (int hf = 0; hf < 2; ++hf) {
-            uint64_t wa = hf == 0 ? loA : hiA, wb = hf == 0 ? loB : hiB;
-#pragma nounroll
-            for (int bi = 0; bi < BPC / 2; ++bi) {
-                if constexpr (CKPT) {
-#if !PHK_EXP_NO_CKPT_STORE
-#pragma unroll
-                    for (int i = 0; i < SPL; ++i) ck_store(&ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)], L::get(a, i));
-#endif
-                    ck_u += ck_step;
-                }
-                const int E0 = E;
-                const uint32_t ca = (uint32_t)wa & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
-                const uint32_t cb = (uint32_t)wb & (uint32_t)((uint64_t(1) << (2 * T)) - 1u);
-                fold_block(ca, cb);
-                if constexpr (CKPT) {
-                    eb_u[sq_off_e] = (int16_t)(E - E0);
-                    eb_u += nseq;
-                    eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
-                }
-                wa >>= 2 * T;
-                wb >>= 2 * T;
-            }
-        }
-        blk += BPC;
-        if constexpr (CKPT) {
-            ckp += (int64_t)BPC * ck_step;
-            ebp += (int64_t)BPC * nseq;
-        }
-    };
-    int budget = A.loop_budget[0];  // (see KArgs::loop_budget; wave-uniform)
-    for (int pc = 0; blk < nblk; pc += PPB) {
-     if (__builtin_expect(--budget < 0, 0)) break;
-     if constexpr (LEAN && FOLD) {
-         // uni2 waves read both rows by scalar loads for as long as the pieces are lean (see the one-state-per-lane
-         // loop below: no wait for the checkpoint stores; each piece is landed before the next is requested)
-         if (uni2 && lean_ok && lean_piece(blk)) {
-             const ScalarPieces spA = scalar_pieces(pieces), spB = scalar_pieces_of_lane(pieces, 63);
-             PieceWords nA = spA[pc], nB = spB[pc];
-             do {
-                 PieceWords cA = nA, cB = nB;
-                 asm volatile("" : "+s"(cA.x), "+s"(cA.y), "+s"(cA.z), "+s"(cA.w), "+s"(cB.x), "+s"(cB.y), "+s"(cB.z), "+s"(cB.w) : : "memory");
-                 nA = spA[pc + 1 < npieces ? pc + 1 : npieces - 1];
-                 nB = spB[pc + 1 < npieces ? pc + 1 : npieces - 1];
-                 fold_piece((uint64_t)cA.x | ((uint64_t)cA.y << 32), (uint64_t)cA.z | ((uint64_t)cA.w << 32),
-                            (uint64_t)cB.x | ((uint64_t)cB.y << 32), (uint64_t)cB.z | ((uint64_t)cB.w << 32));
-                 ++pc;
-             } while (lean_piece(blk) && --budget >= 0);
-             if (blk >= nblk || budget < 0) break;
-             pnext = pieces[pc < npieces ? pc : npieces - 1];
-         }
-     }
-     if constexpr (LEAN && DENSE && PHK_DENSE_UNI != 0 && PHK_UNI_SLOAD != 0) {
-         // Such a wave reads its observation words by SCALAR loads for as long as the pieces are lean: s_load counts
-         // in lgkmcnt, so the wait for the piece requested ahead no longer drains the checkpoint stores (vmcnt counts
-         // loads and stores alike on gfx9, and the compiler cannot count the stores of a piece through its branches:
-         // one store round trip per 64 sites).  No vector load is issued or consumed inside this loop; the piece
-         // after it (warm-up boundary, row tail) is requested again for the general path below.
-         if (uni && lean_ok && lean_piece(blk)) {
-             const ScalarPieces sp = scalar_pieces(pieces);
-             PieceWords snext = sp[pc];
-             do {
-                 PieceWords sc = snext;
-                 // land this piece BEFORE the next one is requested: scalar loads return out of order, s_waitcnt
-                 // lgkmcnt(0) is the only wait they have, and it would wait for the piece requested ahead as well
-                 asm volatile("" : "+s"(sc.x), "+s"(sc.y), "+s"(sc.z), "+s"(sc.w) : : "memory");
-                 snext = sp[pc + 1 < npieces ? pc + 1 : npieces - 1];
-                 uni_piece((uint64_t)sc.x | ((uint64_t)sc.y << 32), (uint64_t)sc.z | ((uint64_t)sc.w << 32));
-                 ++pc;
-             } while (lean_piece(blk) && --budget >= 0);
-             if (blk >= nblk || budget < 0) break;
-             pnext = pieces[pc < npieces ? pc : npieces - 1];
-         }
-     }
-     const uint4 c0 = pnext, c1 = nx1, c2 = nx2, c3 = nx3;
-     if constexpr (PPB == 4) {  // one wait for all four: none of them is "maybe in flight" inside the q loop
-         asm volatile("" ::"v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w),
-                      "v"(c2.x), "v"(c2.y), "v"(c2.z), "v"(c2.w), "v"(c3.x), "v"(c3.y), "v"(c3.z), "v"(c3.w));
-     }
-     pnext = pieces[pc + PPB < npieces ? pc + PPB : npieces - 1];
-     if constexpr (PPB == 4) {
-         nx1 = pieces[pc + 5 < npieces ? pc + 5 : npieces - 1];
-         nx2 = pieces[pc + 6 < npieces ? pc + 6 : npieces - 1];
-         nx3 = pieces[pc + 7 < npieces ? pc + 7 : npieces - 1];
-     }
-#pragma nounroll
-     for (int q = 0; q < PPB && blk < nblk; ++q) {
-      const uint4 pcur = PPB == 1 ? c0 : (q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3)));
-      const int bend = blk + BPC < nblk ? blk + BPC : nblk;
-      if constexpr (LEAN) {
-          if (lean_ok && lean_piece(blk)) {
-              if (DENSE && PHK_DENSE_UNI != 0 && uni) {
-                  uni_piece((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32),
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32));
-                  continue;
-              }
-              if constexpr (CKPT) {
-                  if (A.seg_blocks > 0) {  // segments are whole pieces: a segment can only start with the piece
-                      if (seg_left == 0) {
-                          if (active && rank == 0) *esp = E;
-                          esp += nseq;
-                          seg_left = A.seg_blocks;
-                      }
-                      seg_left -= BPC;
-                  }
-              }
-              real* ck_u = (real*)A.ckpt + (int64_t)blk * ck_step;
-              int16_t* eb_u = A.eblk + (int64_t)blk * nseq;
-              uint32_t w0 = pcur.x, w1 = pcur.y, w2 = pcur.z, w3 = pcur.w;
-#pragma nounroll
-              for (int bi = 0; bi < BPC; ++bi) {
-                  if constexpr (CKPT) {
-#if !PHK_EXP_NO_CKPT_STORE
-#pragma unroll
-                      for (int i = 0; i < SPL; ++i) ck_store(&ck_u[ck_off_e + (unsigned)(i / 4) * ck_piece_e + (unsigned)(i % 4)], L::get(a, i));
-#endif
-                      ck_u += ck_step;
-                  }
-                  const int E0 = E;
-                  if constexpr (DENSE) dense_block(w0);
-                  else straight_block(w0);
-                  if constexpr (CKPT) {
-                      eb_u[sq_off_e] = (int16_t)(E - E0);
-                      eb_u += nseq;
-                      eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
-                  }
-                  if constexpr (T == 16) {
-                      w0 = w1; w1 = w2; w2 = w3;
-                  } else {
-                      w0 = __builtin_amdgcn_alignbit(w1, w0, 2 * T);
-                      w1 = __builtin_amdgcn_alignbit(w2, w1, 2 * T);
-                      w2 = __builtin_amdgcn_alignbit(w3, w2, 2 * T);
-                      w3 >>= 2 * T;
-                  }
-              }
-              blk += BPC;
-              if constexpr (CKPT) {
-                  ckp += (int64_t)BPC * ck_step;
-                  ebp += (int64_t)BPC * nseq;
-              }
-              continue;
-          }
-      }
-      for (int bi = 0; blk < bend; ++blk, ++bi) {
-        const int tw = (bi * T) & 15;  // first site of the block inside its word
-        const int wsel = (bi * T) >> 4;
-        const uint32_t wcur = wsel == 0 ? pcur.x : (wsel == 1 ? pcur.y : (wsel == 2 ? pcur.z : pcur.w));
-        if constexpr (CKPT) {
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < SPL; ++i) ck_store(&ckp[L::ck_elem(i, nseq)], L::get(a, i));
-            }
-            ckp += ck_step;
-        }
-        const int E0 = E;
-        if constexpr (CKPT) {
-            if (A.seg_blocks > 0) {
-                if (seg_left == 0) {
-                    if (active && rank == 0) *esp = E;
-                    esp += nseq;
-                    seg_left = A.seg_blocks;
-                }
-                --seg_left;
-            }
-        }
-        const uint32_t codes = wcur >> (2 * tw);
-        const bool full = blk < nfull && blk != blkW;  // T sites, no warm-up boundary inside
-        const int ns = blk < nfull ? T : tail;
-        if (DENSE && full) {
-            dense_block(codes);
-        } else if (full) {
-            // full block, no warm-up boundary inside: one straight-line basic block of T sites, so
-            // the scheduler can lift every emission ds_read to the top and overlap sites
-#if PHK_EMIS_AHEAD >= 2
-            // emission rows requested PHK_EMIS_AHEAD sites ahead (a ring; the indices are constants after
-            // unrolling): an LDS round trip is ~300 cycles here, more than the ~280 one site takes
-            constexpr int AH = PHK_EMIS_AHEAD < T ? PHK_EMIS_AHEAD : T - 1;
-            V ring[AH + 1][NP];
-#pragma unroll
-            for (int j = 0; j < AH; ++j) lane.emis((codes >> (2 * j)) & 3, ring[j]);
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (i + AH < T) lane.emis((codes >> (2 * (i + AH))) & 3, ring[(i + AH) % (AH + 1)]);
-                real sc;
-                const int ex = lane.fwd_site(a, ring[i % (AH + 1)], sc, rescale_after<NRM>(i));
-                E += ex;
-                if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
-            straight_block(codes);
-#endif
-        } else {
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (i < ns) {
-                    real sc;
-                    V e[NP];
-                    lane.emis((codes >> (2 * i)) & 3, e);
-                    const int ex = lane.fwd_site(a, e, sc, rescale_after<NRM>(i));
-                    E += ex;
-                    if (NRM > 1 && rescale_after<NRM>(i)) ex_slack = min(ex_slack, ex - RISK_EXP);
-                    if (blk == blkW && i == iW) {
-                        const double cW = (double)lane.total(a);
-                        llW = log(cW) + (double)E * LN2;
-                    }
-                }
-            }
-        }
-        if constexpr (CKPT) {
-            if (active && rank == 0) *ebp = (int16_t)(E - E0);
-            ebp += nseq;
-            eb_min = (E - E0) < eb_min ? (E - E0) : eb_min;
-        }
-      }
-     }
-    }
-    if (__builtin_expect(budget < 0, 0)) {  // out of its iteration budget: flag, record, leave (the call has failed)
-        report_overrun(A, 1, seq, blk);
-        return;
-    }
-    const double cend = (double)lane.total(a);  // Ltot == 0: sum(pi)
-    if (NRM > 1 && active && rank == 0 && A.risk != nullptr &&
-        (ex_slack < 0 || !(cend > 0.0)))
-        atomicOr(A.risk, FLAG_UNDERFLOW);
-    if (active && rank == 0) {
-        A.ll[sm.oseq] = log(cend) + (double)E * LN2 - llW;  // (the caller's order: see SeqMap)
-        if constexpr (CKPT) {
-            A.aux[seq].inv_end = 1.0 / cend;
-            A.aux[seq].e_end = E;
-            A.aux[seq].eb_min = eb_min;
-        }
-    }
+#define PHK_KERNEL_MR false
+#include "fwd_kernel_body.inc"
+#undef PHK_KERNEL_MR
+}
+template <typename real, int K, int R, int T, int NRM, bool CKPT>
+__global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void fwd_kernel_mr(KArgs A) {
+#define PHK_KERNEL_MR true
+#include "fwd_kernel_body.inc"
+#undef PHK_KERNEL_MR
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2741,280 +2180,15 @@ __global__ __launch_bounds__(NT_MAX, (bwd_waves_per_simd<real, K, R, T, SEG>()))
 // ---------------------------------------------------------------------------------------------
 template <typename real, int K, int R, int NRM>
 __global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void bscan_kernel(KArgs A, int64_t seg_sites, void* bseg_out, int32_t* fseg_out) {
-    using L = Lane<real, K, R>;
-    using V = typename L::V;
-    constexpr int SPL = L::SPL, NP = L::NP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // the scan's wave priority is a launch argument (phk_api.hip: scan_prio_for): its waves share SIMDs with the forward kernel's
-    // (priority PHK_FWD_PRIO), and which of the two kernels should win the issue slots depends on which one the rows make longer
-    if (A.scan_prio >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (A.scan_prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (A.scan_prio == 1) __builtin_amdgcn_s_setprio(1);
-    const int64_t nseq = A.B * A.S;
-    const int rank = threadIdx.x & (R - 1);
-    // (idle waves leave, lane groups are mapped to sequences as in fwd_kernel: see map_group)
-    const SeqMap sm = map_group<real, K, R>(A);
-#ifndef PHK_KEEP_IDLE_WAVES
-    if (sm.idle_wave) return;
-#endif
-    const bool active = sm.active;
-    const int64_t bb = sm.bb, ss = sm.ss, seq = sm.seq;
-
-    L lane;
-    V pi[NP], beta[NP];
-    lane.load((const real*)A.params + bb * A.pstride_b + ss * A.pstride_s, rank,
-              (real*)smem_raw + (size_t)threadIdx.x * L::ETAB_STRIDE, pi);
-    const real* pfb = prefold_block<real>(A, bb, ss);
-    const bool fold_seq = lane.try_fold(pfb != nullptr ? pfb + rank * L::SPL : nullptr);  // (float32: the folded model, see Lane::try_fold)
-    constexpr bool DENSE = has_dense<real, K, R>() && NRM == 4;  // hom-run operators (see dense16)
-    if constexpr (DENSE) lane.template load_dense<true>(A.ops_b + (A.pstride_s != 0 ? bb * A.S + ss : bb) * DENSE_OPS_FLOATS, rank, fold_seq);
-#pragma unroll
-    for (int h = 0; h < NP; ++h) beta[h] = splat<real>(real(0));
-#pragma unroll
-    for (int i = 0; i < SPL; ++i) L::set(beta, i, real(1));
-    const uint32_t* words = A.packed + checked_row(A, ss) * A.Lw;
-    bool uni = false;  // the wave's sequences share their observation row and the emission ratios exist (see fwd_kernel)
-    if constexpr (DENSE && PHK_DENSE_UNI_SCAN != 0) {
-        const int ss0 = __builtin_amdgcn_readfirstlane((int)ss);
-        uni = __all((int)ss == ss0 && (fold_seq || lane.etab[0] > RATIO_MIN_EMIS0)) != 0;
-    }
-    int F = 0;
-    int f_slack = 1 << 20;  // dense kernel: smallest distance to its threshold of an exponent a rescale removed (see fwd_kernel: ex_slack)
-    int hom_run = 0;  // dense kernel: rescale debt (hom sites stepped over since the last rescale; uniform path: + 16 per het / missing site)
-    // 32-bit wave-uniform bookkeeping, no division inside the loop (see fwd_kernel)
-    const int nw = (int)((A.Ltot + 15) / 16);
-    const int seg_words = (int)(seg_sites >> 4);  // segments are whole words (SEG_SITES = 512)
-    const int tail = (int)(A.Ltot - (int64_t)(nw - 1) * 16);  // sites in the last word (1..16)
-    // the first segment start met from the right: the largest multiple of seg_sites below Ltot
-    int sb = (int)((A.Ltot - 1) / seg_sites);            // its segment index (0: none to store)
-    int w_store = sb * seg_words - 1;                    // store before processing this word ...
-    // 16-byte pieces (4 words) requested one piece ahead; word loop nested in the piece loop (see fwd_kernel)
-    const uint4* pieces = (const uint4*)words;
-    int w = nw - 1;
-    int pc = w >> 2;
-    uint4 pnext = pieces[pc > 0 ? pc : 0];
-    if constexpr (sizeof(real) == 4 || PHK_EXP_LAND_F64) asm volatile("" ::"v"(pnext.x), "v"(pnext.y), "v"(pnext.z), "v"(pnext.w));  // see fwd_kernel
-    // one whole word (16 sites, right to left) of the other layouts: straight-line, next emission row in flight
-    auto straight_word = [&](const uint32_t codes) {
-        V ec[NP];
-        lane.emis(codes >> 30, ec);
-#pragma unroll
-        for (int j = 15; j >= 0; --j) {
-            V en[NP];
-            if (j > 0) lane.emis((codes >> (2 * (j - 1))) & 3, en);
-            F += lane.bt_site(beta, ec, rescale_after<NRM>(j));
-            if (j > 0) {
-#pragma unroll
-                for (int h = 0; h < NP; ++h) ec[h] = en[h];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // one whole word (16 sites, right to left) of the one-state-per-lane layout: dense M_h^16 / M_h^8 / M_h^4 /
-    // M_h^2 steps where every sequence of the wave is hom over the sites they cover (see fwd_kernel)
-    auto dense_word = [&](const uint32_t codes) {
-        if constexpr (DENSE) {
-            if (PHK_DENSE16 && __all(codes == 0u)) {  // (one rescale per PHK_DENSE_RESCALE_SITES hom sites: see fwd_kernel)
-                beta[0][0] = dense16(beta[0][0], lane.D16);
-                hom_run += 16;
-                if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                    hom_run = 0;
-                    const int ex = lane.rescale(beta);
-                    F += ex;
-                    f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
-                }
-                return;
-            }
-#pragma unroll
-            for (int h8 = 1; h8 >= 0; --h8) {
-                if (PHK_DENSE8 && __all(((codes >> (16 * h8)) & 0xffffu) == 0u)) {
-                    beta[0][0] = dense16(beta[0][0], lane.P[7]);
-                    hom_run += 8;
-                    if (hom_run >= PHK_DENSE_RESCALE_SITES) {
-                        hom_run = 0;
-                        const int ex = lane.rescale(beta);
-                        F += ex;
-                        f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
-                    }
-                    continue;
-                }
-                hom_run = 0;
-#pragma unroll
-                for (int g = 2 * h8 + 1; g >= 2 * h8; --g) {
-                    const uint32_t c4 = (codes >> (8 * g)) & 0xffu;
-                    if (__all(c4 == 0u)) {
-                        beta[0][0] = dense16(beta[0][0], lane.P[3]);
-                    } else {
-#pragma unroll
-                        for (int hh = 1; hh >= 0; --hh) {
-                            const uint32_t c2 = (c4 >> (4 * hh)) & 0xfu;
-                            if (__all(c2 == 0u)) {
-                                beta[0][0] = dense16(beta[0][0], lane.P[1]);
-                            } else {
-                                V e[NP];
-                                lane.emis(c2 >> 2, e);
-                                lane.bt_site(beta, e, false);
-                                lane.emis(c2 & 3, e);
-                                lane.bt_site(beta, e, false);
-                            }
-                        }
-                    }
-                    const int ex = lane.rescale(beta);
-                    F += ex;
-                    f_slack = min(f_slack, ex - RISK_EXP_F32);
-                }
-            }
-        }
-    };
-    // One whole word of a wave whose sequences share their observation row (see fwd_kernel, uni_block): right to left,
-    // a run is "a het or missing site (multiply by its ratio FIRST: b <- M_h (ratio .* b)), then the hom sites to its
-    // left", one dense M_h^n step; the leading run of a word may start with a hom site.
-    auto uni_word = [&](const uint32_t rem) {
-        if constexpr (DENSE) {
-            float x = beta[0][0];
-            auto resc = [&](float& y) -> int {
-                const int ex = lane.rescale1(y);
-                F += ex;
-                f_slack = min(f_slack, ex - RISK_EXP_DEFERRED_F32);
-                return 0;
-            };
-            if (__builtin_expect(rem == 0u, 1)) {  // all hom
-                x = dense16(x, lane.D16);
-                hom_run += 16;
-            } else {
-                hom_run = lane.template half_step<false>(x, rem >> 16, hom_run, resc);
-                if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
-                hom_run = lane.template half_step<false>(x, rem & 0xffffu, hom_run, resc);
-            }
-            if (__builtin_expect(hom_run >= PHK_DENSE_RESCALE_SITES, 0)) hom_run = resc(x);
-            beta[0][0] = x;
-        }
-    };
-    // seed of segment sb (beta at site sb * seg_sites) before word w_store is processed
-    auto store_seed = [&]() {
-        real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
-        fseg_out[(int64_t)sb * nseq + seq] = F;
-        --sb;
-        w_store -= seg_words;
-    };
-    int budget = A.loop_budget[2];  // (see KArgs::loop_budget)
-    for (; w >= 0; --pc) {
-      if (__builtin_expect(--budget < 0, 0)) break;
-      if constexpr (DENSE && PHK_DENSE_LEAN != 0 && PHK_DENSE_UNI_SCAN != 0 && PHK_UNI_SLOAD != 0) {
-          // A wave whose sequences share their observation row reads it by scalar loads from here to the row's start
-          // (every piece left of the one holding the last word is four whole words): see fwd_kernel.  The four words
-          // of a piece, right to left, as the high halves of two 64-bit scalars shifted up.
-          if (uni && w == pc * 4 + 3 && w < nw - 1 && (seg_words & 3) == 0) {
-              const ScalarPieces sp = scalar_pieces(pieces);
-              PieceWords snext = sp[pc];
-              do {
-                  PieceWords sc = snext;
-                  asm volatile("" : "+s"(sc.x), "+s"(sc.y), "+s"(sc.z), "+s"(sc.w) : : "memory");  // (land it before the next request)
-                  snext = sp[pc > 0 ? pc - 1 : 0];
-                  // a seed is stored before word w_store = sb * seg_words - 1 (-1 when none is left: no test of sb), with
-                  // segments of whole pieces always the first word of a piece met from the right: one test per piece
-                  if (__builtin_expect(w == w_store, 0)) store_seed();
-#pragma nounroll
-                  for (int hf = 0; hf < 2; ++hf) {
-                      uint64_t cw = hf == 0 ? ((uint64_t)sc.z | ((uint64_t)sc.w << 32)) : ((uint64_t)sc.x | ((uint64_t)sc.y << 32));
-#pragma nounroll
-                      for (int k = 0; k < 2; ++k, --w) {
-                          uint32_t rem = (uint32_t)(cw >> 32);
-                          asm volatile("" : "+s"(rem));  // (a 32-bit scalar of its own: "rem == 0" is then s_cmp_eq_u32, not a 64-bit VALU compare of cw)
-                          uni_word(rem);
-                          cw <<= 32;
-                      }
-                  }
-                  --pc;
-              } while (w >= 0 && --budget >= 0);
-              break;
-          }
-      }
-      const uint4 pcur = pnext;
-      pnext = pieces[pc > 0 ? pc - 1 : 0];
-      if constexpr (DENSE ? PHK_DENSE_LEAN != 0 : PHK_FWD_LEAN != 0) {
-          // lean path (see fwd_kernel): a piece of four whole words, none of them the row's last (partial)
-          // word: the words rotate through one register, the segment-start test is the only one left
-          if (w == pc * 4 + 3 && w < nw - 1) {
-              if (DENSE && PHK_DENSE_UNI_SCAN != 0 && uni) {
-                  uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.z) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.w) << 32);
-                  uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.x) |
-                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.y) << 32);
-#pragma nounroll
-                  for (int k = 0; k < 4; ++k, --w) {
-                      if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
-                          real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
-#pragma unroll
-                          for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
-                          fseg_out[(int64_t)sb * nseq + seq] = F;
-                          --sb;
-                          w_store -= seg_words;
-                      }
-                      uni_word((uint32_t)(hi >> 32));
-                      hi = (hi << 32) | (lo >> 32);
-                      lo <<= 32;
-                  }
-                  continue;
-              }
-              uint32_t w3 = pcur.w, w2 = pcur.z, w1 = pcur.y, w0 = pcur.x;
-#pragma nounroll
-              for (int k = 0; k < 4; ++k, --w) {
-                  if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
-                      real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
-#pragma unroll
-                      for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
-                      fseg_out[(int64_t)sb * nseq + seq] = F;
-                      --sb;
-                      w_store -= seg_words;
-                  }
-                  if constexpr (DENSE) dense_word(w3);
-                  else straight_word(w3);
-                  w3 = w2; w2 = w1; w1 = w0;
-              }
-              continue;
-          }
-      }
-      for (const int wlo = pc * 4; w >= wlo; --w) {
-        const int wsel = w & 3;
-        const uint32_t codes = wsel == 0 ? pcur.x : (wsel == 1 ? pcur.y : (wsel == 2 ? pcur.z : pcur.w));
-        if (w == w_store && sb > 0) {  // beta now stands at site (w + 1) * 16 = sb * seg_sites
-            if (active) {
-                real* dst = (real*)bseg_out + ((int64_t)sb * nseq + seq) * K + rank * SPL;
-#pragma unroll
-                for (int i = 0; i < SPL; ++i) dst[i] = L::get(beta, i);
-                if (rank == 0) fseg_out[(int64_t)sb * nseq + seq] = F;
-            }
-            --sb;
-            w_store -= seg_words;
-        }
-        const int ns = w == nw - 1 ? tail : 16;
-        if (DENSE && ns == 16) {
-            dense_word(codes);
-        } else if (ns == 16) {
-            straight_word(codes);
-        } else {
-#pragma unroll
-            for (int j = 15; j >= 0; --j) {
-                if (j < ns) {
-                    V e[NP];
-                    lane.emis((codes >> (2 * j)) & 3, e);
-                    F += lane.bt_site(beta, e, rescale_after<NRM>(j));
-                }
-            }
-        }
-
-      }
-    }
-    if (__builtin_expect(budget < 0, 0)) {
-        report_overrun(A, 4, seq, w);
-        return;
-    }
-    if constexpr (DENSE) {  // the scan's own underflow flag (its seeds feed the segment sweep; see fwd_kernel for the thresholds)
-        if (active && rank == 0 && A.risk != nullptr && f_slack < 0) atomicOr(A.risk, FLAG_UNDERFLOW);
-    }
+#define PHK_KERNEL_MR false
+#include "bscan_kernel_body.inc"
+#undef PHK_KERNEL_MR
+}
+template <typename real, int K, int R, int NRM>
+__global__ __launch_bounds__(NT_MAX, (scan_waves_per_simd<real, K, R>())) void bscan_kernel_mr(KArgs A, int64_t seg_sites, void* bseg_out, int32_t* fseg_out) {  // (see fwd_kernel_mr)
+#define PHK_KERNEL_MR true
+#include "bscan_kernel_body.inc"
+#undef PHK_KERNEL_MR
 }
 
 // gacc [B*S, 6, K] (unit 0) + part [units - 1, range, 6, K] (the other units, added in unit order:
@@ -3122,7 +2296,7 @@ __global__ void take_flags_kernel(int* flags, double* dst) {
 
 // Dense hom-run operators for the one-state-per-lane kernels (K = 16, float32): one workgroup per parameter block,
 // thread (r, c) owns entry [r][c].  M_h = A diag(emis0), A[r][c] = b[c] (r > c), d[c] (r == c), u[r] v[c] (r < c)
-// (hmm.py:52-65 written out as a matrix); powers 1..8 and 16 accumulated in float64 from float64 factors and rounded
+// (hmm.py:52-65 written out as a matrix); powers 1..8 and 16 (and the eighth power of the missing-site step) accumulated in float64 from float64 factors and rounded
 // once -- the same operator is applied thousands of times along a row, so an error in it acts like a perturbation of
 // the parameters (coherent over the sequence), not like round-off.  Both forms are written lane-major:
 //   ops_f[blk][n][i][j] = (M_h^n)[j][i]   (forward kernel: lane i holds column i)
@@ -3179,10 +2353,22 @@ __global__ __launch_bounds__(256) void dense_ops_kernel(const float* __restrict_
     emit(7, p8);
     __syncthreads();
     emit(8, mul(4, 4));
+    // eight missing sites: (M_h diag(rmis))^8 with the ratio as the kernels hold it (Lane::load_dense / fold_emissions)
+    const double rm = (fold && pf) ? (double)pf[4 * 16 + c] : (double)(float)(1.0 / (double)e0f);
+    __syncthreads();
+    Mx[0][r][c] = m * rm;
+    __syncthreads();
+    const double a2 = mul(0, 0);
+    Mx[1][r][c] = a2;
+    __syncthreads();
+    const double a4 = mul(1, 1);
+    Mx[2][r][c] = a4;
+    __syncthreads();
+    emit(9, mul(2, 2));
 }
 
-// (nonhom: optional device counter of the sites that are not hom -- the one property of the data the static plan looks at, see
-// phk_api.hip static_plan)
+// (nonhom: optional device counters [2] -- the sites that are not hom, the one property of the data the static plan looks at
+// (phk_api.hip static_plan), and the 8-site halves that are missing throughout (phk_api.hip mask_runs))
 __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t L, uint32_t* __restrict__ out,
                             int64_t Lw, unsigned long long* __restrict__ nonhom) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3206,6 +2392,9 @@ __global__ void pack_kernel(const int8_t* __restrict__ data, int64_t N, int64_t 
         if (left < 16) nh &= left > 0 ? ((1u << (2 * left)) - 1u) : 0u;
         const int n = __builtin_popcount(nh);
         if (n) atomicAdd(nonhom, (unsigned long long)n);
+        // [1]: halves that are missing throughout (inside the row: padding decodes as missing too)
+        const int nm = ((word & 0xffffu) == 0xAAAAu && left >= 8 ? 1 : 0) + ((word >> 16) == 0xAAAAu && left >= 16 ? 1 : 0);
+        if (nm) atomicAdd(nonhom + 1, (unsigned long long)nm);
     }
 }
 #endif  // PHK_WITH_PACK

@@ -631,6 +631,74 @@ def test_dense_kernels_random_shapes(seed):
     assert not eng.underflow_risk()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PHK_MASK_FUZZ_SEEDS", "18"))))
+def test_missing_run_kernels_on_masked_rows(seed):
+    """Rows with an accessibility mask: runs of tens to hundreds of missing windows covering 10-40 % of every row.  A kernel
+    object whose rows hold such runs (pack_kernel counts the 8-site halves that are missing throughout) launches the
+    one-state-per-lane kernels in their *_mr form, which step over such a half with ONE operator, (M_h diag(1 / emis0))^8,
+    instead of eight dense steps (Lane::half_step; the production shape at 7 % hets with a quarter of every row masked: 11.5 ->
+    5.6 ms per step).  Seeded draws of row length, warm-up boundary, het rate, mask, batch, checkpoint interval and launch form
+    (dense forward kernel + serial sweep; segmented: dense forward kernel beside the dense beta scan; hybrid with the dense scan),
+    each against the float64 oracle -- and against the same kernel object with the form switched off (PHK_MASK_RUNS=0): both
+    inside the bars, and NOT the same bits, or the operator never ran."""
+    rng = np.random.default_rng(9000 + seed)
+    L = int(rng.choice([513, 1024, 1500, int(rng.integers(600, 3001)), int(rng.integers(600, 3001))]))
+    W = int(rng.choice([0, 0, int(rng.integers(0, L // 2)), 64, 500 if L > 1000 else 8]))
+    B, S = int(rng.integers(4, 14)), int(rng.integers(1, 5))
+    N = S + int(rng.integers(0, 2))
+    het = float(rng.choice([0.0, 0.02, 0.05, 0.1]))
+    data = (rng.uniform(size=(N, L)) < het).astype(np.int8)
+    frac, run = float(rng.choice([0.1, 0.25, 0.4])), int(rng.choice([20, 60, 200]))
+    for r in range(N):
+        pos = int(rng.geometric(frac / (run * (1 - frac))))
+        while pos < L:
+            n = int(rng.geometric(1.0 / run))
+            data[r, pos:pos + n] = -1
+            pos += n + int(rng.geometric(frac / (run * (1 - frac))))
+    data[:, 0] = np.maximum(data[:, 0], 0)
+    inds = rng.integers(0, N, size=S)
+    P = _params(16, B, 1, seed=seed)
+    T = int(rng.choice([8, 16]))
+    form = int(rng.integers(3))
+    hybrid = None
+    if form == 2 and S >= 2:
+        hybrid = f"{int(rng.choice([2, 4]))}:16:{B * int(rng.integers(1, S))}:4:16"
+    out = {}
+    for on in ("1", "0"):
+        os.environ["PHK_MASK_RUNS"] = on  # (read when the kernel object is created)
+        try:
+            eng = _engine(16, data, False)
+        finally:
+            os.environ.pop("PHK_MASK_RUNS", None)
+        eng.set_autotune(False)
+        eng.set_rescale_interval(4)
+        if form == 0:
+            eng.set_variant(16, T)
+        elif hybrid is None:
+            eng.set_plan(1, R=4 if T == 16 else 2, T=T, R_forward=16, R_scan=16)
+        if hybrid:
+            os.environ["PHK_HYBRID"] = hybrid
+        try:
+            ll, g = _run(eng, P, inds, W)
+            ll0 = _run(eng, P, inds, W, grad=False)
+        finally:
+            os.environ.pop("PHK_HYBRID", None)
+        assert not eng.underflow_risk()
+        out[on] = (ll, g, ll0)
+    ll_ref, g_ref = cport.batch(P, data, inds, W)
+    for on in ("1", "0"):
+        ll, g, ll0 = out[on]
+        np.testing.assert_allclose(ll, ll_ref, rtol=1e-5, atol=max(1e-5, 2e-8 * L))
+        np.testing.assert_allclose(ll0, ll_ref, rtol=1e-5, atol=max(1e-5, 1e-7 * L))
+        worst = _grad_within_fuzz_bound(g, g_ref, P, P, data, inds, W, False)
+        print(f"masked rows seed={seed} B={B} S={S} L={L} W={W} het={het} mask={frac}/{run} T={T} form={form} hybrid={hybrid} mr={on}: err/bound {worst:.2f}")
+        assert worst < 1.0
+    n8 = (L // 8) * 8
+    halves = int((data[np.unique(inds), :n8].reshape(-1, n8 // 8, 8) == -1).all(-1).sum())  # 8-site halves missing throughout
+    if halves >= 3:
+        assert not np.array_equal(out["1"][2], out["0"][2]), "the *_mr kernels returned the bits of the plain ones: the operator never ran"
+
+
 @pytest.mark.parametrize("T", [8, 16])
 def test_scalar_row_loops_at_piece_and_segment_edges(T):
     """The one-state-per-lane kernels read a wave-uniform observation row by scalar loads inside loops that cover only
