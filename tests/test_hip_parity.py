@@ -697,6 +697,25 @@ def test_missing_run_kernels_on_masked_rows(seed):
     halves = int((data[np.unique(inds), :n8].reshape(-1, n8 // 8, 8) == -1).all(-1).sum())  # 8-site halves missing throughout
     if halves >= 3:
         assert not np.array_equal(out["1"][2], out["0"][2]), "the *_mr kernels returned the bits of the plain ones: the operator never ran"
+    # the kernel object's own choice (no override): the *_mr form where more than 0.5 % of ALL its sites sit in such halves
+    eng = _engine(16, data, False)
+    eng.set_autotune(False)
+    eng.set_rescale_interval(4)
+    eng.set_variant(16, T)
+    share = 8.0 * int((data[:, :n8].reshape(N, n8 // 8, 8) == -1).all(-1).sum()) / data.size
+    want = "1" if share > 0.005 else "0"
+    for on in ("1", "0"):
+        os.environ["PHK_MASK_RUNS"] = on
+        try:
+            forced = _engine(16, data, False)
+        finally:
+            os.environ.pop("PHK_MASK_RUNS", None)
+        forced.set_autotune(False)
+        forced.set_rescale_interval(4)
+        forced.set_variant(16, T)
+        same = np.array_equal(_run(eng, P, inds, W, grad=False), _run(forced, P, inds, W, grad=False))
+        if halves >= 3 and abs(share - 0.005) > 1e-4:
+            assert same == (on == want), (share, on, same)
 
 
 @pytest.mark.parametrize("T", [8, 16])
